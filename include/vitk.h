@@ -1,0 +1,235 @@
+/*
+ * vitk — C ABI of the MI355X (gfx950) kernel library behind the ViT/CvT hot path.
+ *
+ * The reference (newbee1905/vit) has no FFI: its hot path is a chain of PyTorch ATen
+ * calls inside nn.Module.forward bodies.  Each entry point below replaces the ATen
+ * call(s) of one reference call site (cited as file:line under the reference
+ * checkout) and is what the drop-in layer modules (vit_amd/layers) bind through ctypes.
+ *
+ * Conventions
+ *  - every buffer is caller-allocated DEVICE memory; nothing is allocated or freed here;
+ *  - every call is asynchronous on the `stream` argument (a hipStream_t passed as void*)
+ *    and never synchronises; distinct streams may be used from distinct threads;
+ *  - `dtype` arguments: 0 = float32, 1 = bfloat16.  Parameters of norms, biases,
+ *    LayerScale vectors and statistics (mean/rstd/lse) are always float32;
+ *  - return value: 0 on success, a negative vitk_status otherwise (HIP runtime errors are
+ *    reported as VITK_ERR_HIP - hipError_t); vitk_strerror() gives the text.  Shapes and
+ *    alignments are validated on the host before any kernel is launched.
+ */
+#ifndef VITK_H
+#define VITK_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VITK_VERSION 100
+
+enum vitk_status {
+	VITK_OK = 0,
+	VITK_ERR_SHAPE = -1,      /* a dimension is non-positive or exceeds what the kernel supports */
+	VITK_ERR_DTYPE = -2,      /* dtype code not supported by this entry point */
+	VITK_ERR_ALIGN = -3,      /* pointer / leading dimension not aligned as the kernel requires */
+	VITK_ERR_NULL = -4,       /* a required pointer is null */
+	VITK_ERR_UNSUPPORTED = -5,/* combination of options not implemented */
+	VITK_ERR_HIP = -1000      /* -1000 - hipError_t */
+};
+
+enum vitk_dtype { VITK_F32 = 0, VITK_BF16 = 1 };
+
+/* activation codes (layers/transformers.py:26-33; F.gelu is the exact erf form) */
+enum vitk_act { VITK_ACT_NONE = 0, VITK_ACT_GELU = 1, VITK_ACT_SILU = 2, VITK_ACT_RELU = 3, VITK_ACT_RELU6 = 4 };
+
+/* operand layouts of vitk_gemm: which index is contiguous in memory */
+enum vitk_layout {
+	VITK_K_MAJOR = 0,   /* A(m,k) = A[m*lda + k]      B(n,k) = B[n*ldb + k] */
+	VITK_MN_MAJOR = 1   /* A(m,k) = A[k*lda + m]      B(n,k) = B[k*ldb + n] */
+};
+
+/* epilogues of vitk_gemm; acc = sum_k A(m,k) B(n,k), v = acc + bias[n] (bias optional) */
+enum vitk_epilogue {
+	VITK_EPI_NONE = 0,      /* C = v                                                        */
+	VITK_EPI_ACT = 1,       /* C = act(v);  out2 (optional) = v  (the pre-activation)        */
+	VITK_EPI_RESIDUAL = 2,  /* C = aux + gamma[n] * v   (gamma optional = 1)                 */
+	VITK_EPI_ACTGRAD = 3    /* C = v * act'(aux)        (aux = saved pre-activation)         */
+};
+
+const char* vitk_strerror(int status);
+int vitk_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * GEMM with fused epilogue:  C[M,N] (+)= epilogue( sum_k A(m,k) * B(n,k) ).
+ * Replaces every nn.Linear on the path and its autograd mm pair:
+ *   forward  y = x W^T + b   models/vit.py:30,39,47,65; layers/attention.py:17-18,28,47,57-64,68-70,92;
+ *                            layers/transformers.py:36-40,46,54          (A = x K-major, B = W K-major)
+ *   dgrad    dx = dy W                                                   (A = dy K-major, B = W MN-major)
+ *   wgrad    dW = dy^T x                                                 (A = dy MN-major, B = x MN-major)
+ * and fuses bias, activation (layers/transformers.py:48-52), LayerScale + residual add
+ * (layers/vit.py:44-47,52-55) and the activation derivative of the backward into the epilogue.
+ *
+ * Patch embedding (models/vit.py:46-52, layers/embeddings.py:7-16) is the same GEMM with an
+ * im2col-free A operand: with patch_grid > 0, A is an NCHW image batch [*, img_c, img_hw, img_hw]
+ * and A(m,k) = image[m / P2][c][py*p + i][px*p + j], P2 = patch_grid^2, p = img_hw / patch_grid,
+ * (py,px) = divmod(m % P2, patch_grid), (c,i,j) = unravel(k, (img_c,p,p)).  With tokens_per_image > 0
+ * output row m is stored at row m + m / tokens_per_image + 1 (one class-token row is left free in
+ * front of every image) and pos[(1 + m % tokens_per_image) * N + n] is added to v.
+ *
+ * in_dtype is the dtype of A, B and aux; out_dtype of C and out2.  bias, gamma and pos are float32.
+ * The bf16 MFMA path needs K % 8 == 0, 16-byte aligned A/B and leading dimensions that are
+ * multiples of 8 elements; other bf16 shapes and all float32 inputs run on the generic
+ * (float32-MFMA) path.  accumulate != 0 adds into C (out_dtype must be float32).
+ */
+typedef struct vitk_gemm_desc {
+	const void* A;
+	const void* B;
+	void* C;
+	int64_t M, N, K;
+	int64_t lda, ldb, ldc;
+	int32_t a_layout, b_layout;
+	int32_t in_dtype, out_dtype;
+	int32_t epilogue, act;
+	int32_t accumulate;
+	int32_t patch_grid;        /* 0 = A is a plain matrix */
+	int32_t img_c, img_hw;
+	int32_t tokens_per_image;  /* 0 = no row remap / no pos add */
+	int32_t reserved;
+	const float* bias;         /* [N] or null */
+	const float* gamma;        /* [N] or null (VITK_EPI_RESIDUAL) */
+	const float* pos;          /* [(tokens_per_image+1), N] or null */
+	const void* aux;           /* [M, ld_aux] residual or pre-activation */
+	int64_t ld_aux;
+	void* out2;                /* [M, ld_out2] optional second output */
+	int64_t ld_out2;
+} vitk_gemm_desc;
+
+int vitk_gemm(const vitk_gemm_desc* desc, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Row normalisation.  rows = B*N tokens, d = d_model.
+ * LayerNorm: nn.LayerNorm injected through config.norm (layers/vit.py:15,20,38,49; eps 1e-5).
+ * RMSNorm: layers/norm.py:19-31 (fp32 internal, y = x * rsqrt(mean(x^2)+eps) * (unit_offset + w)).
+ * If `res` is non-null the kernel first forms s = x + res, writes s to `sum_out` (the new
+ * residual stream, may alias x) and normalises s.
+ * Backward: dx = d(loss)/d(x) of y = norm(x); if `dres` is non-null it is added to dx
+ * (gradient flowing around the norm on the residual stream).  dgamma / dbeta are float32
+ * [d] and are ACCUMULATED into (the caller zeroes them), through per-block partial sums.
+ */
+int vitk_layernorm_fwd(const void* x, const void* res, const float* gamma, const float* beta,
+	void* y, void* sum_out, float* mean, float* rstd, int64_t rows, int64_t d, float eps, int dtype, void* stream);
+int vitk_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
+	const void* dres, void* dx, float* dgamma, float* dbeta, int64_t rows, int64_t d, int dtype, void* stream);
+int vitk_rmsnorm_fwd(const void* x, const void* res, const float* weight, void* y, void* sum_out, float* rstd,
+	int64_t rows, int64_t d, float eps, int unit_offset, int dtype, void* stream);
+int vitk_rmsnorm_bwd(const void* dy, const void* x, const float* weight, const float* rstd, const void* dres,
+	void* dx, float* dweight, int64_t rows, int64_t d, int unit_offset, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Multi-head attention core: F.scaled_dot_product_attention(q,k,v,is_causal=False)
+ * (layers/attention.py:39-43,84-88) together with the head split/merge rearranges
+ * (layers/attention.py:31-33,45,80-82,90).
+ * q is [B, Sq, *] with row stride ldq; head h occupies columns [h*dh, (h+1)*dh) — i.e. the
+ * 'b s (h d)' layout the projections produce, so q/k/v may be column slices of one fused
+ * [B, S, 3*d_model] buffer.  k, v are [B, Skv, *].  out is [B, Sq, n_head*dh] with row stride ldo.
+ * lse [B, n_head, Sq] float32 = log-sum-exp of the scaled scores, saved for the backward.
+ * scale <= 0 selects 1/sqrt(dh).  Backward needs out and lse of the forward.
+ */
+int vitk_attention_fwd(const void* q, const void* k, const void* v, void* out, float* lse,
+	int64_t B, int64_t n_head, int64_t Sq, int64_t Skv, int64_t dh,
+	int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, float scale, int dtype, void* stream);
+int vitk_attention_bwd(const void* dout, const void* q, const void* k, const void* v, const void* out, const float* lse,
+	void* dq, void* dk, void* dv,
+	int64_t B, int64_t n_head, int64_t Sq, int64_t Skv, int64_t dh,
+	int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t lddq, int64_t lddk, int64_t lddv,
+	float scale, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Bandwidth-bound elementwise / reduction kernels.
+ */
+/* dst[i] = (dst_dtype) src[i] */
+int vitk_cast(const void* src, void* dst, int64_t n, int src_dtype, int dst_dtype, void* stream);
+/* out[n] (+)= sum_m x[m*ld + n]  — bias gradient of a Linear (autograd of addmm) */
+int vitk_colsum(const void* x, float* out, int64_t M, int64_t N, int64_t ld, int accumulate, int dtype, void* stream);
+/* Gated FFN (layers/transformers.py:48-50): u = [gate | up] with row stride ld_u, a = gate * act(up). */
+int vitk_gated_act_fwd(const void* u, void* a, int64_t M, int64_t F, int64_t ld_u, int act, int dtype, void* stream);
+/* du = [da * act(up) | da * gate * act'(up)] */
+int vitk_gated_act_bwd(const void* da, const void* u, void* du, int64_t M, int64_t F, int64_t ld_u, int act, int dtype, void* stream);
+/* y = act(x) and dx = dy * act'(x) as stand-alone kernels (used when no GEMM epilogue is available) */
+int vitk_act_fwd(const void* x, void* y, int64_t n, int act, int dtype, void* stream);
+int vitk_act_bwd(const void* dy, const void* x, void* dx, int64_t n, int act, int dtype, void* stream);
+/* Inverted dropout (nn.Dropout, layers/vit.py:18,23,43,51; layers/transformers.py:42-43,54-55):
+ * y[i] = keep(i) ? x[i] / (1 - p) : 0 with keep(i) drawn from a counter-based hash of (seed, i).
+ * The backward is the same call on dy with the same seed (the mask is regenerated, never stored).
+ * The random stream differs from torch's Philox stream, so training-mode dropout matches the
+ * reference in distribution only. */
+int vitk_dropout(const void* x, void* y, int64_t n, float p, uint64_t seed, int dtype, void* stream);
+/* y = res + gamma[col] * x (gamma nullable); rows x d.  layers/vit.py:44-47,52-55 when not fused in a GEMM */
+int vitk_scale_residual(const void* x, const void* res, const float* gamma, void* y, int64_t rows, int64_t d, int dtype, void* stream);
+/* LayerScale backward: dbranch = gamma * dy ; dgamma[col] += sum_rows dy * branch */
+int vitk_layerscale_bwd(const void* dy, const void* branch, const float* gamma, void* dbranch, float* dgamma,
+	int64_t rows, int64_t d, int dtype, void* stream);
+/* Class-token rows (models/vit.py:49-52): x[b, 0, :] = class_token + pos_embed[0]; x is [B, tokens, d]. */
+int vitk_cls_rows(void* x, const float* class_token, const float* pos_embed, int64_t B, int64_t tokens, int64_t d, int dtype, void* stream);
+/* dpos[t, :] (+)= sum_b dx[b, t, :]  (gradient of the broadcast pos_embed add; row 0 is also d class_token) */
+int vitk_batch_sum(const void* dx, float* dpos, int64_t B, int64_t rows, int64_t d, int accumulate, int dtype, void* stream);
+/* im2col of non-overlapping patches (layers/embeddings.py:7-16) and its inverse scatter; used by the
+ * backward of the patch embedding only — the forward gathers inside the GEMM. */
+int vitk_patchify(const void* images, void* patches, int64_t B, int64_t C, int64_t HW, int64_t n_patch, int dtype, void* stream);
+int vitk_unpatchify(const void* patches, void* images, int64_t B, int64_t C, int64_t HW, int64_t n_patch, int dtype, void* stream);
+/* Copy rows [1, tokens) of every image of x[B, tokens, d] into a dense [B*(tokens-1), d] matrix. */
+int vitk_drop_cls_rows(const void* x, void* out, int64_t B, int64_t tokens, int64_t d, int dtype, void* stream);
+/* Token mean pool x[B, S, d] -> y[B, d] and its backward (models/cvt.py:105). */
+int vitk_mean_pool_fwd(const void* x, void* y, int64_t B, int64_t S, int64_t d, int dtype, void* stream);
+int vitk_mean_pool_bwd(const void* dy, void* dx, int64_t B, int64_t S, int64_t d, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Loss heads.
+ * Cross entropy with label smoothing, mean reduction (main.py:106-109), fused with the DeiT
+ * soft-distillation term (deit_trainer.py:30-45):
+ *   loss = (1-alpha) * CE(s, y) + alpha * tau^2 * KL(softmax(t/tau) || softmax(s/tau)) / B
+ * teacher == null (or alpha == 0) gives plain cross entropy.  Writes loss[0] (float32; the caller
+ * zeroes it) and dlogits = d loss / d s in the dtype of the logits.
+ */
+int vitk_ce_kd_loss(const void* logits, const int64_t* labels, const void* teacher, float* loss, void* dlogits,
+	int64_t B, int64_t C, float label_smoothing, float alpha, float tau, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Fused AdamW over one flat float32 parameter buffer (torch.optim.AdamW semantics, main.py:100):
+ * p *= 1 - lr*wd; m,v updated; p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps).  `wd_mask` (nullable,
+ * one byte per element) selects which elements are decayed (utils.py:102-121 param groups).
+ * `p_bf16` (nullable) receives a bfloat16 copy of the updated parameters for the next forward.
+ * grad_scale multiplies the gradient first (1/world_size after a sum all-reduce).
+ */
+int vitk_adamw(float* p, const float* g, float* m, float* v, const uint8_t* wd_mask, void* p_bf16, int64_t n,
+	float lr, float beta1, float beta2, float eps, float weight_decay, int64_t step, float grad_scale, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * CvT pieces.
+ * Depthwise 3x3 convolution on token-major activations (layers/attention.py:61-62,73-78):
+ * x [B, H*W, C] -> y [B, Ho*Wo, C], weight [C, 1, ks, ks] float32 or bf16 as `dtype`, no bias.
+ */
+int vitk_dwconv_fwd(const void* x, const void* w, void* y, int64_t B, int64_t H, int64_t W, int64_t C,
+	int64_t ks, int64_t stride, int64_t pad, int dtype, void* stream);
+int vitk_dwconv_bwd(const void* dy, const void* x, const void* w, void* dx, float* dw, int64_t B, int64_t H, int64_t W, int64_t C,
+	int64_t ks, int64_t stride, int64_t pad, int dtype, void* stream);
+/* im2col for the overlapping conv token embedding (layers/embeddings.py:21): x NCHW -> cols [B*Ho*Wo, C*ks*ks]
+ * (the convolution itself is vitk_gemm on cols) and col2im (scatter-add) for its input gradient.
+ * With tokens_in != 0 the input is token-major [B, H*W, C] (the layout CvT blocks produce), so the
+ * 'b (h w) c -> b c h w' rearrange of models/cvt.py:91,98 is folded into the gather. */
+int vitk_im2col(const void* x, void* cols, int64_t B, int64_t C, int64_t H, int64_t W, int64_t ks, int64_t stride, int64_t pad,
+	int tokens_in, int dtype, void* stream);
+int vitk_col2im(const void* cols, void* dx, int64_t B, int64_t C, int64_t H, int64_t W, int64_t ks, int64_t stride, int64_t pad,
+	int tokens_in, int dtype, void* stream);
+/* BatchNorm over token-major activations x[rows, C] (nn.BatchNorm2d after the conv, layers/embeddings.py:22,26-27;
+ * rows = B*Ho*Wo).  training: batch statistics (biased variance for normalisation, unbiased for the running
+ * update with `momentum`), save_mean/save_rstd [C] float32 kept for the backward.  eval: running statistics. */
+int vitk_batchnorm_fwd(const void* x, const float* gamma, const float* beta, float* running_mean, float* running_var,
+	void* y, float* save_mean, float* save_rstd, int64_t rows, int64_t C, float eps, float momentum, int training, int dtype, void* stream);
+int vitk_batchnorm_bwd(const void* dy, const void* x, const float* gamma, const float* save_mean, const float* save_rstd,
+	void* dx, float* dgamma, float* dbeta, int64_t rows, int64_t C, int training, int dtype, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VITK_H */

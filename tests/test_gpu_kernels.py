@@ -1,0 +1,263 @@
+"""GPU parity: each vitk kernel (through the C ABI) against the CPU oracle on the same seeded inputs.
+
+Tolerances (max|a-b| / max|b|): float32 1e-4; bfloat16 2e-2 (the bars the north star sets).
+bf16 kernels are compared with the oracle evaluated in float64 on the SAME bf16-rounded inputs."""
+import math
+
+import pytest
+import torch
+
+from conftest import relerr
+from oracle import vit_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+TOL = {torch.float32: 1e-4, torch.bfloat16: 2e-2}
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+def rnd(shape, dtype, dev, scale=1.0, seed=0):
+	g = torch.Generator().manual_seed(seed)
+	x = (torch.randn(shape, generator=g) * scale).to(dtype)
+	return x.to(dev), x.double()
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (197, 384, 192), (300, 130, 72), (64, 1000, 768), (50, 10, 48), (512, 768, 3072), (33, 7, 5)])
+@pytest.mark.parametrize("mode", ["fwd", "dgrad", "wgrad"])
+def test_gemm_layouts(gpu, dtype, M, N, K, mode):
+	from vit_amd import ops
+	import vit_amd._lib as L
+	if mode == "fwd":
+		a, ar = rnd((M, K), dtype, gpu, seed=1)
+		b, br = rnd((N, K), dtype, gpu, seed=2)
+		c = torch.empty((M, N), dtype=dtype, device=gpu)
+		ops.gemm(a, b, c, M, N, K, K, K, N)
+		ref = ar @ br.t()
+	elif mode == "dgrad":  # C[M,N] = A[M,K] @ W[K,N]  (B is MN-major)
+		a, ar = rnd((M, K), dtype, gpu, seed=1)
+		b, br = rnd((K, N), dtype, gpu, seed=2)
+		c = torch.empty((M, N), dtype=dtype, device=gpu)
+		ops.gemm(a, b, c, M, N, K, K, N, N, b_layout=L.MN_MAJOR)
+		ref = ar @ br
+	else:  # C[M,N] = A[K,M]^T @ B[K,N], float32 output
+		a, ar = rnd((K, M), dtype, gpu, seed=1)
+		b, br = rnd((K, N), dtype, gpu, seed=2)
+		c = torch.empty((M, N), dtype=torch.float32, device=gpu)
+		ops.gemm(a, b, c, M, N, K, M, N, N, a_layout=L.MN_MAJOR, b_layout=L.MN_MAJOR)
+		ref = ar.t() @ br
+	tol = TOL[dtype] if (mode != "wgrad" or dtype == torch.float32) else 1e-3  # wgrad output is f32: only accumulation-order error
+	assert relerr(c, ref) < tol
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_exact_integers(gpu, dtype):
+	"""Small-integer operands: every product and sum is exact, so any fragment-layout or swizzle error shows as a wrong integer.
+	A is the identity-like selector with an asymmetric B (catches transposed outputs)."""
+	from vit_amd import ops
+	import vit_amd._lib as L
+	M, N, K = 256, 384, 320
+	g = torch.Generator().manual_seed(3)
+	a = torch.randint(-3, 4, (M, K), generator=g).to(dtype)
+	b = torch.randint(-3, 4, (N, K), generator=g).to(dtype)
+	c = torch.empty((M, N), dtype=dtype, device=gpu)
+	ops.gemm(a.to(gpu), b.to(gpu), c, M, N, K, K, K, N)
+	ref = a.double() @ b.double().t()
+	assert torch.equal(c.cpu().double(), ref.to(dtype).double())  # exact sum, one rounding to the output type
+	# MN-major operands (transposing LDS reads)
+	at, bt = a.t().contiguous(), b.t().contiguous()
+	c2 = torch.empty((M, N), dtype=torch.float32, device=gpu)
+	ops.gemm(at.to(gpu), bt.to(gpu), c2, M, N, K, M, N, N, a_layout=L.MN_MAJOR, b_layout=L.MN_MAJOR)
+	assert torch.equal(c2.cpu().double(), ref)
+	c3 = torch.empty((M, N), dtype=dtype, device=gpu)
+	ops.gemm(a.to(gpu), bt.to(gpu), c3, M, N, K, K, N, N, b_layout=L.MN_MAJOR)
+	assert torch.equal(c3.cpu().double(), ref.to(dtype).double())
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("act", ["gelu", "silu", "relu", "relu6"])
+def test_gemm_epilogues(gpu, dtype, act):
+	from vit_amd import ops
+	import vit_amd._lib as L
+	M, N, K = 200, 256, 128
+	x, xr = rnd((M, K), dtype, gpu, seed=1)
+	w, wr = rnd((N, K), dtype, gpu, 0.1, seed=2)
+	bias = torch.randn(N, generator=torch.Generator().manual_seed(3))
+	code = L.ACT_CODES[act]
+	y, pre = ops.linear_fwd(x, w, bias.to(gpu), act=code, save_pre=True)
+	pre_ref = xr @ wr.t() + bias.double()
+	assert relerr(pre, pre_ref) < TOL[dtype]
+	assert relerr(y, O.act_fwd(pre.cpu().double(), act)) < TOL[dtype]
+	# residual + LayerScale epilogue
+	res, rr = rnd((M, N), dtype, gpu, seed=4)
+	gamma = torch.rand(N, generator=torch.Generator().manual_seed(5)) + 0.5
+	y2 = ops.linear_fwd(x, w, bias.to(gpu), residual=res, gamma=gamma.to(gpu))
+	assert relerr(y2, rr + gamma.double() * pre_ref) < TOL[dtype]
+	# dgrad with the activation derivative in the epilogue
+	dy, dyr = rnd((M, K), dtype, gpu, seed=6)          # gradient wrt the NEXT layer's input == this layer's activation output
+	w2, w2r = rnd((K, N), dtype, gpu, 0.1, seed=7)     # next layer weight [out=K, in=N]
+	du = ops.linear_dgrad(dy, w2, act=code, pre=pre)
+	assert relerr(du, (dyr @ w2r) * O.act_grad(pre.cpu().double(), act)) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("kind", ["layernorm", "rmsnorm"])
+@pytest.mark.parametrize("rows,d", [(37, 768), (9, 192), (5, 40), (3, 50), (11, 2048)])
+def test_norms(gpu, dtype, kind, rows, d):
+	from vit_amd import ops
+	x, xr = rnd((rows, d), dtype, gpu, 1.5, seed=1)
+	res, rr = rnd((rows, d), dtype, gpu, seed=2)
+	dy, dyr = rnd((rows, d), dtype, gpu, seed=3)
+	dres, dresr = rnd((rows, d), dtype, gpu, seed=4)
+	g = torch.Generator().manual_seed(5)
+	w = torch.randn(d, generator=g) * 0.3 + (1.0 if kind == "layernorm" else 0.0)
+	b = torch.randn(d, generator=g) * 0.3
+	eps = 1e-5 if kind == "layernorm" else 1e-6
+	y, s, mean, rstd = ops.norm_fwd(x, w.to(gpu), b.to(gpu) if kind == "layernorm" else None, kind, eps, True, res=res)
+	s_ref = (xr + rr).to(dtype).double()
+	assert relerr(s, s_ref) < 1e-6 if dtype == torch.float32 else relerr(s, s_ref) == 0.0
+	if kind == "layernorm":
+		y_ref, m_ref, r_ref = O.layernorm_fwd(s_ref, w.double(), b.double(), eps)
+		assert relerr(mean, m_ref) < 1e-5
+	else:
+		y_ref, r_ref = O.rmsnorm_fwd(s_ref, w.double(), eps, True)
+	assert relerr(rstd, r_ref) < 1e-5
+	assert relerr(y, y_ref) < TOL[dtype]
+	dx, dw, db = ops.norm_bwd(dy, s, w.to(gpu), mean, rstd, kind, True, dres=dres)
+	if kind == "layernorm":
+		dx_ref, dw_ref, db_ref = O.layernorm_bwd(dyr, s_ref, w.double(), m_ref, r_ref)
+		assert relerr(db, db_ref) < 1e-4
+	else:
+		dx_ref, dw_ref = O.rmsnorm_bwd(dyr, s_ref, w.double(), r_ref, True)
+	assert relerr(dx, dx_ref + dresr) < TOL[dtype]
+	assert relerr(dw, dw_ref) < 1e-4
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,h,Sq,Skv,dh", [(2, 3, 65, 65, 64), (2, 12, 197, 197, 64), (3, 4, 17, 17, 12), (2, 2, 50, 13, 24), (2, 6, 4, 1, 64), (1, 1, 300, 300, 64), (2, 2, 16, 4, 32)])
+def test_attention(gpu, dtype, B, h, Sq, Skv, dh):
+	from vit_amd import ops
+	d = h * dh
+	q, qr = rnd((B * Sq, d), dtype, gpu, seed=1)
+	k, kr = rnd((B * Skv, d), dtype, gpu, seed=2)
+	v, vr = rnd((B * Skv, d), dtype, gpu, seed=3)
+	do, dor = rnd((B * Sq, d), dtype, gpu, seed=4)
+	out, lse = ops.attention_fwd(q, k, v, B, h, Sq, Skv, dh)
+	q4 = O.split_heads(qr.reshape(B, Sq, d), h)
+	k4 = O.split_heads(kr.reshape(B, Skv, d), h)
+	v4 = O.split_heads(vr.reshape(B, Skv, d), h)
+	o_ref, lse_ref = O.sdpa_fwd(q4, k4, v4)
+	assert relerr(out, O.merge_heads(o_ref).reshape(B * Sq, d)) < TOL[dtype]
+	assert relerr(lse, lse_ref) < 1e-4
+	dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+	ops.attention_bwd(do, q, k, v, out, lse, dq, dk, dv, B, h, Sq, Skv, dh)
+	do4 = O.split_heads(dor.reshape(B, Sq, d), h)
+	dq_r, dk_r, dv_r = O.sdpa_bwd(do4, q4, k4, v4, o_ref, lse_ref)
+	if Skv == 1:
+		# one key: softmax is the constant 1, dq and dk are exact zeros in exact arithmetic and rounding noise here
+		noise = 1e-4 if dtype == torch.float32 else 5e-2
+		assert dq.abs().max().item() < noise and dk.abs().max().item() < noise
+	else:
+		assert relerr(dq, O.merge_heads(dq_r).reshape(B * Sq, d)) < TOL[dtype]
+		assert relerr(dk, O.merge_heads(dk_r).reshape(B * Skv, d)) < TOL[dtype]
+	assert relerr(dv, O.merge_heads(dv_r).reshape(B * Skv, d)) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_attention_strided_qkv(gpu, dtype):
+	"""q/k/v as column slices of one fused [rows, 3d] buffer (the layout MHA uses)."""
+	from vit_amd import ops
+	B, h, S, dh = 2, 2, 33, 64
+	d = h * dh
+	qkv, qkvr = rnd((B * S, 3 * d), dtype, gpu, seed=1)
+	out, lse = ops.attention_fwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], B, h, S, S, dh)
+	q4, k4, v4 = (O.split_heads(qkvr[:, i * d:(i + 1) * d].reshape(B, S, d), h) for i in range(3))
+	o_ref, lse_ref = O.sdpa_fwd(q4, k4, v4)
+	assert relerr(out, O.merge_heads(o_ref).reshape(B * S, d)) < TOL[dtype]
+	do, dor = rnd((B * S, d), dtype, gpu, seed=4)
+	dqkv = torch.empty_like(qkv)
+	ops.attention_bwd(do, qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], out, lse, dqkv[:, :d], dqkv[:, d:2 * d], dqkv[:, 2 * d:], B, h, S, S, dh)
+	refs = O.sdpa_bwd(O.split_heads(dor.reshape(B, S, d), h), q4, k4, v4, o_ref, lse_ref)
+	for i, r in enumerate(refs):
+		assert relerr(dqkv[:, i * d:(i + 1) * d], O.merge_heads(r).reshape(B * S, d)) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_elementwise(gpu, dtype):
+	from vit_amd import ops
+	import vit_amd._lib as L
+	lib = L.load()
+	x, xr = rnd((37, 96), dtype, gpu, 2.0, seed=1)
+	# colsum
+	assert relerr(ops.colsum(x), xr.sum(0)) < 1e-4
+	assert relerr(ops.colsum(x[:, :10]), xr[:, :10].sum(0)) < 1e-4
+	# gated act fwd/bwd
+	for act in ("silu", "gelu"):
+		code = L.ACT_CODES[act]
+		a = ops.gated_act_fwd(x, 48, code)
+		assert relerr(a, xr[:, :48] * O.act_fwd(xr[:, 48:], act)) < TOL[dtype]
+		da, dar = rnd((37, 48), dtype, gpu, seed=2)
+		du = ops.gated_act_bwd(da, x, 48, code)
+		ref = torch.cat([dar * O.act_fwd(xr[:, 48:], act), dar * xr[:, :48] * O.act_grad(xr[:, 48:], act)], 1)
+		assert relerr(du, ref) < TOL[dtype]
+	# scale_residual + layerscale bwd
+	res, rr = rnd((37, 96), dtype, gpu, seed=3)
+	gamma = torch.rand(96, generator=torch.Generator().manual_seed(4)) + 0.5
+	assert relerr(ops.scale_residual(x, res, gamma.to(gpu)), rr + gamma.double() * xr) < TOL[dtype]
+	db, dg = ops.layerscale_bwd(res, x, gamma.to(gpu))
+	assert relerr(db, gamma.double() * rr) < TOL[dtype]
+	assert relerr(dg, (rr * xr).sum(0)) < 1e-4
+	# cast round trip
+	y = ops.cast(ops.cast(x, torch.float32), dtype)
+	assert torch.equal(y, x)
+	# dropout: keep fraction and scaling; backward regenerates the same mask
+	big = torch.ones(1 << 20, dtype=dtype, device=gpu)
+	out = ops.DropoutFn.apply(big, 0.3, 12345)
+	keep = (out != 0).float().mean().item()
+	assert abs(keep - 0.7) < 5e-3
+	assert relerr(out[out != 0], torch.full((1,), 1 / 0.7).expand(int((out != 0).sum()))) < TOL[dtype]
+	out2 = ops.DropoutFn.apply(big, 0.3, 12345)
+	assert torch.equal(out, out2)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", ["a05_t1", "a03_t3_ls01", "a1_t2"])
+def test_ce_kd_loss_golden(gpu, dtype, case):
+	from conftest import load_golden, sub
+	from vit_amd import ops
+	g, meta = load_golden("deit_loss")
+	c = sub(g, case)
+	alpha, tau, ls = meta["cases"][case]
+	s = c["student"].to(dtype).to(gpu).requires_grad_(True)
+	loss = ops.deit_loss(s, c["y"].to(gpu), c["teacher"].to(dtype).to(gpu), alpha, tau, ls)
+	loss.backward()
+	if dtype == torch.float32:
+		assert relerr(loss, c["loss"]) < 1e-4
+		assert relerr(s.grad, c["dstudent"]) < 1e-4
+	else:
+		ref_l = O.deit_loss_fwd(s.detach().cpu().double(), c["y"], c["teacher"].to(dtype).double(), alpha, tau, ls)
+		assert relerr(loss, ref_l) < 1e-3
+		assert relerr(s.grad, c["dstudent"]) < 2e-2
+	# plain cross entropy
+	s2 = c["student"].to(gpu).requires_grad_(True)
+	l2 = ops.cross_entropy(s2, c["y"].to(gpu), ls)
+	l2.backward()
+	assert relerr(l2, O.cross_entropy_fwd(c["student"], c["y"], ls)) < 1e-4
+	assert relerr(s2.grad, O.cross_entropy_bwd(c["student"], c["y"], ls)) < 1e-4
+
+
+def test_adamw_golden(gpu):
+	from conftest import load_golden
+	import vit_amd._lib as L
+	g, meta = load_golden("adamw")
+	lib = L.load()
+	p = g["p0"].to(gpu).clone()
+	m = torch.zeros_like(p)
+	v = torch.zeros_like(p)
+	p16 = torch.empty(p.shape, dtype=torch.bfloat16, device=gpu)
+	for step in range(3):
+		gr = g[f"g{step}"].to(gpu)
+		L.check(lib.vitk_adamw(L.ptr(p), L.ptr(gr), L.ptr(m), L.ptr(v), None, L.ptr(p16), p.numel(), meta["lr"], meta["betas"][0], meta["betas"][1],
+			meta["eps"], meta["weight_decay"], step + 1, 1.0, L.stream()))
+		assert relerr(p, g[f"p{step + 1}"]) < 1e-5
+	assert torch.equal(p16, p.to(torch.bfloat16))

@@ -1,0 +1,46 @@
+// C ABI of the attention core: argument validation and dispatch between the bf16 MFMA kernels and
+// the generic vector-ALU kernels.
+#include "attention.h"
+
+static int check_common(const AttnArgs& a) {
+	VITK_REQUIRE(a.B > 0 && a.n_head > 0 && a.Sq > 0 && a.Skv > 0 && a.dh > 0, VITK_ERR_SHAPE);
+	VITK_REQUIRE(a.dh <= 64, VITK_ERR_SHAPE);
+	VITK_REQUIRE(a.B <= 65535 && a.n_head <= 65535, VITK_ERR_SHAPE);
+	const int64_t hd = (int64_t)a.n_head * a.dh;
+	VITK_REQUIRE(a.ldq >= hd && a.ldk >= hd && a.ldv >= hd && a.ldo >= hd, VITK_ERR_SHAPE);
+	return VITK_OK;
+}
+
+extern "C" int vitk_attention_fwd(const void* q, const void* k, const void* v, void* out, float* lse, int64_t B, int64_t n_head, int64_t Sq,
+	int64_t Skv, int64_t dh, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, float scale, int dtype, void* stream) {
+	VITK_REQUIRE(q && k && v && out && lse, VITK_ERR_NULL);
+	VITK_REQUIRE(B < (1ll << 31) && n_head < (1ll << 31) && Sq < (1ll << 31) && Skv < (1ll << 31) && dh < (1ll << 31), VITK_ERR_SHAPE);
+	AttnArgs a{};
+	a.q = q; a.k = k; a.v = v; a.out = out; a.out_w = out; a.lse = lse;
+	a.B = (int)B; a.n_head = (int)n_head; a.Sq = (int)Sq; a.Skv = (int)Skv; a.dh = (int)dh;
+	a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo;
+	a.scale = scale > 0.f ? scale : 1.0f / sqrtf((float)dh);
+	int rc = check_common(a);
+	if (rc != VITK_OK) return rc;
+	if (vitk_attention_mfma_ok(a, dtype)) return vitk_attention_mfma(a, false, (hipStream_t)stream);
+	return vitk_attention_generic(a, false, dtype, (hipStream_t)stream);
+}
+
+extern "C" int vitk_attention_bwd(const void* dout, const void* q, const void* k, const void* v, const void* out, const float* lse, void* dq,
+	void* dk, void* dv, int64_t B, int64_t n_head, int64_t Sq, int64_t Skv, int64_t dh, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
+	int64_t lddq, int64_t lddk, int64_t lddv, float scale, int dtype, void* stream) {
+	VITK_REQUIRE(dout && q && k && v && out && lse && dq && dk && dv, VITK_ERR_NULL);
+	VITK_REQUIRE(B < (1ll << 31) && n_head < (1ll << 31) && Sq < (1ll << 31) && Skv < (1ll << 31) && dh < (1ll << 31), VITK_ERR_SHAPE);
+	AttnArgs a{};
+	a.q = q; a.k = k; a.v = v; a.out = out; a.dout = dout; a.lse = const_cast<float*>(lse);
+	a.dq = dq; a.dk = dk; a.dv = dv;
+	a.B = (int)B; a.n_head = (int)n_head; a.Sq = (int)Sq; a.Skv = (int)Skv; a.dh = (int)dh;
+	a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.lddq = lddq; a.lddk = lddk; a.lddv = lddv;
+	a.scale = scale > 0.f ? scale : 1.0f / sqrtf((float)dh);
+	int rc = check_common(a);
+	if (rc != VITK_OK) return rc;
+	const int64_t hd = (int64_t)a.n_head * a.dh;
+	VITK_REQUIRE(lddq >= hd && lddk >= hd && lddv >= hd, VITK_ERR_SHAPE);
+	if (vitk_attention_mfma_ok(a, dtype)) return vitk_attention_mfma(a, true, (hipStream_t)stream);
+	return vitk_attention_generic(a, true, dtype, (hipStream_t)stream);
+}

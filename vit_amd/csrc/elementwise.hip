@@ -1,0 +1,532 @@
+// Bandwidth-bound elementwise, gather and reduction kernels of the ViT/CvT hot path.
+// All of them stream 16 bytes per lane when pointers and extents allow, else fall back to
+// one element per lane.
+#include "vitk_common.h"
+
+namespace {
+
+// ---- generic unary / binary maps -----------------------------------------------------------------
+// F: float f(float a, float b, int64 index).  b is read only if B != nullptr.
+template <typename TA, typename TB, typename TO, int VEC, typename F>
+__global__ __launch_bounds__(256) void map2_kernel(const TA* __restrict__ a, const TB* __restrict__ b, TO* __restrict__ o, int64_t n, F f) {
+	const int64_t stride = (int64_t)gridDim.x * blockDim.x * VEC;
+	for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * VEC; i < n; i += stride) {
+		float va[VEC], vb[VEC], vo[VEC];
+		load_vec<TA, VEC>(a + i, va);
+		if (b != nullptr) load_vec<TB, VEC>(b + i, vb);
+#pragma unroll
+		for (int j = 0; j < VEC; ++j) vo[j] = f(va[j], b != nullptr ? vb[j] : 0.f, i + j);
+		store_vec<TO, VEC>(o + i, vo);
+	}
+}
+
+template <typename TA, typename TB, typename TO, typename F>
+int launch_map2(const void* a, const void* b, void* o, int64_t n, F f, hipStream_t st) {
+	if (n <= 0) return VITK_OK;
+	constexpr int V = 4;
+	const bool vec = (n % V == 0) && vitk_aligned(a, sizeof(TA) * V) && (b == nullptr || vitk_aligned(b, sizeof(TB) * V)) && vitk_aligned(o, sizeof(TO) * V);
+	if (vec) {
+		hipLaunchKernelGGL((map2_kernel<TA, TB, TO, V, F>), dim3(vitk_stream_grid(n / V, 256)), dim3(256), 0, st, (const TA*)a, (const TB*)b, (TO*)o, n, f);
+	} else {
+		hipLaunchKernelGGL((map2_kernel<TA, TB, TO, 1, F>), dim3(vitk_stream_grid(n, 256)), dim3(256), 0, st, (const TA*)a, (const TB*)b, (TO*)o, n, f);
+	}
+	VITK_CHECK_LAUNCH();
+	return VITK_OK;
+}
+
+struct Ident {
+	__device__ float operator()(float a, float, int64_t) const { return a; }
+};
+struct ActF {
+	int act;
+	__device__ float operator()(float a, float, int64_t) const { return act_apply(a, act); }
+};
+struct ActB {
+	int act;
+	__device__ float operator()(float dy, float x, int64_t) const { return dy * act_deriv(x, act); }
+};
+
+// ---- dropout: keep(i) from splitmix64(seed + i) ---------------------------------------------------
+struct DropF {
+	float p, inv_keep;
+	uint64_t seed;
+	__device__ float operator()(float a, float, int64_t i) const {
+		uint64_t z = seed + (uint64_t)i * 0x9E3779B97F4A7C15ull;
+		z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+		z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+		z = z ^ (z >> 31);
+		const float u = (float)(z >> 40) * (1.0f / 16777216.0f);
+		return u >= p ? a * inv_keep : 0.f;
+	}
+};
+
+// ---- column sum: out[n] += sum_m x[m*ld + n] ------------------------------------------------------
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, float* out, int64_t M, int64_t N, int64_t ld) {
+	__shared__ float red[4][64 * VEC];
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	const int64_t col = ((int64_t)blockIdx.x * 64 + lane) * VEC;
+	float acc[VEC];
+#pragma unroll
+	for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
+	if (col < N) {
+		for (int64_t m = (int64_t)blockIdx.y * 4 + wave; m < M; m += (int64_t)gridDim.y * 4) {
+			float v[VEC];
+			load_vec<T, VEC>(x + m * ld + col, v);
+#pragma unroll
+			for (int j = 0; j < VEC; ++j) acc[j] += v[j];
+		}
+	}
+#pragma unroll
+	for (int j = 0; j < VEC; ++j) red[wave][lane * VEC + j] = acc[j];
+	__syncthreads();
+	if (wave == 0 && col < N) {
+#pragma unroll
+		for (int j = 0; j < VEC; ++j) {
+			const float s = red[0][lane * VEC + j] + red[1][lane * VEC + j] + red[2][lane * VEC + j] + red[3][lane * VEC + j];
+			atomicAdd(&out[col + j], s);
+		}
+	}
+}
+
+template <typename T>
+int launch_colsum(const void* x, float* out, int64_t M, int64_t N, int64_t ld, hipStream_t st) {
+	constexpr int V = VecOf<T>::N;
+	const bool vec = (N % V == 0) && (ld % V == 0) && vitk_aligned(x, 16);
+	const int64_t strips = vitk_cdiv(N, 64 * (vec ? V : 1));
+	int64_t slabs = std::min<int64_t>(vitk_cdiv(M, 4), std::max<int64_t>(1, 2048 / strips));
+	if (vec)
+		hipLaunchKernelGGL((colsum_kernel<T, V>), dim3((unsigned)strips, (unsigned)slabs), dim3(256), 0, st, (const T*)x, out, M, N, ld);
+	else
+		hipLaunchKernelGGL((colsum_kernel<T, 1>), dim3((unsigned)strips, (unsigned)slabs), dim3(256), 0, st, (const T*)x, out, M, N, ld);
+	VITK_CHECK_LAUNCH();
+	return VITK_OK;
+}
+
+// ---- gated FFN activation ---------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void gated_fwd_kernel(const T* __restrict__ u, T* __restrict__ a, int64_t M, int64_t F, int64_t ld_u, int act) {
+	const int64_t n = M * F;
+	for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+		const int64_t m = i / F, f = i - m * F;
+		const float gate = to_f32<T>(u[m * ld_u + f]);
+		const float up = to_f32<T>(u[m * ld_u + F + f]);
+		a[i] = from_f32<T>(gate * act_apply(up, act));
+	}
+}
+template <typename T>
+__global__ __launch_bounds__(256) void gated_bwd_kernel(const T* __restrict__ da, const T* __restrict__ u, T* __restrict__ du, int64_t M, int64_t F,
+	int64_t ld_u, int act) {
+	const int64_t n = M * F;
+	for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+		const int64_t m = i / F, f = i - m * F;
+		const float gate = to_f32<T>(u[m * ld_u + f]);
+		const float up = to_f32<T>(u[m * ld_u + F + f]);
+		const float g = to_f32<T>(da[i]);
+		du[m * ld_u + f] = from_f32<T>(g * act_apply(up, act));
+		du[m * ld_u + F + f] = from_f32<T>(g * gate * act_deriv(up, act));
+	}
+}
+
+// ---- y = res + gamma[col] * x -----------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void scale_residual_kernel(const T* __restrict__ x, const T* __restrict__ res, const float* __restrict__ gamma,
+	T* __restrict__ y, int64_t n, int64_t d) {
+	for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+		const float g = gamma ? gamma[i % d] : 1.f;
+		y[i] = from_f32<T>(to_f32<T>(res[i]) + g * to_f32<T>(x[i]));
+	}
+}
+
+// dbranch = gamma * dy ; dgamma[col] += sum_rows dy * branch
+template <typename T>
+__global__ __launch_bounds__(256) void layerscale_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ branch, const float* __restrict__ gamma,
+	T* __restrict__ dbranch, float* dgamma, int64_t rows, int64_t d) {
+	// block x: 256 columns; block y: row slab
+	const int64_t col = (int64_t)blockIdx.x * 256 + threadIdx.x;
+	if (col >= d) return;
+	const float g = gamma[col];
+	float acc = 0.f;
+	for (int64_t r = blockIdx.y; r < rows; r += gridDim.y) {
+		const float v = to_f32<T>(dy[r * d + col]);
+		acc += v * to_f32<T>(branch[r * d + col]);
+		dbranch[r * d + col] = from_f32<T>(g * v);
+	}
+	atomicAdd(&dgamma[col], acc);
+}
+
+// ---- class-token rows and positional-embedding gradient ------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void cls_rows_kernel(T* x, const float* __restrict__ cls, const float* __restrict__ pos, int64_t B, int64_t tokens, int64_t d) {
+	const int64_t n = B * d;
+	for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+		const int64_t b = i / d, c = i - b * d;
+		x[b * tokens * d + c] = from_f32<T>(cls[c] + pos[c]);
+	}
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void batch_sum_kernel(const T* __restrict__ dx, float* dpos, int64_t B, int64_t per_image, int accumulate, int64_t bchunk) {
+	const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= per_image) return;
+	const int64_t b0 = (int64_t)blockIdx.y * bchunk;
+	const int64_t b1 = b0 + bchunk < B ? b0 + bchunk : B;
+	float acc = 0.f;
+	for (int64_t b = b0; b < b1; ++b) acc += to_f32<T>(dx[b * per_image + i]);
+	if (gridDim.y == 1 && !accumulate)
+		dpos[i] = acc;
+	else
+		atomicAdd(&dpos[i], acc);
+}
+
+// ---- patch gather / scatter (layers/embeddings.py:7-16) ------------------------------------------
+template <typename T, bool SCATTER>
+__global__ __launch_bounds__(256) void patchify_kernel(const T* __restrict__ src, T* __restrict__ dst, int64_t B, int C, int HW, int P) {
+	const int p = HW / P;
+	const int64_t K = (int64_t)C * p * p;
+	const int64_t n = B * P * P * K;
+	for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+		const int64_t m = i / K;
+		const int k = (int)(i - m * K);
+		const int64_t b = m / (P * P);
+		const int t = (int)(m - b * P * P);
+		const int py = t / P, px = t - py * P;
+		const int c = k / (p * p), rem = k - c * p * p;
+		const int ii = rem / p, jj = rem - ii * p;
+		const int64_t img = ((b * C + c) * HW + (py * p + ii)) * HW + (px * p + jj);
+		if (SCATTER)
+			dst[img] = src[i];
+		else
+			dst[i] = src[img];
+	}
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void drop_cls_kernel(const T* __restrict__ x, T* __restrict__ out, int64_t B, int64_t tokens, int64_t d) {
+	const int64_t per = (tokens - 1) * d;
+	const int64_t n = B * per;
+	for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+		const int64_t b = i / per, r = i - b * per;
+		out[i] = x[b * tokens * d + d + r];
+	}
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void mean_pool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t B, int64_t S, int64_t d) {
+	const int64_t n = B * d;
+	for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+		const int64_t b = i / d, c = i - b * d;
+		float acc = 0.f;
+		for (int64_t s = 0; s < S; ++s) acc += to_f32<T>(x[(b * S + s) * d + c]);
+		y[i] = from_f32<T>(acc / (float)S);
+	}
+}
+template <typename T>
+__global__ __launch_bounds__(256) void mean_pool_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, int64_t B, int64_t S, int64_t d) {
+	const int64_t n = B * S * d;
+	const float inv = 1.f / (float)S;
+	for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+		const int64_t b = i / (S * d), c = i % d;
+		dx[i] = from_f32<T>(to_f32<T>(dy[b * d + c]) * inv);
+	}
+}
+
+// ---- cross entropy (+ label smoothing) fused with the DeiT soft-distillation term -----------------
+// One wavefront per sample.
+template <typename T>
+__global__ __launch_bounds__(256) void ce_kd_kernel(const T* __restrict__ logits, const int64_t* __restrict__ labels, const T* __restrict__ teacher,
+	float* loss, T* __restrict__ dlogits, int64_t B, int C, float ls, float alpha, float tau) {
+	const int lane = threadIdx.x & 63;
+	const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+	if (row >= B) return;
+	const T* s = logits + row * C;
+	const T* t = teacher ? teacher + row * C : nullptr;
+	const float inv_tau = 1.f / tau;
+	float m1 = -INFINITY, mt = -INFINITY;
+	for (int c = lane; c < C; c += 64) {
+		m1 = fmaxf(m1, to_f32<T>(s[c]));
+		if (t) mt = fmaxf(mt, to_f32<T>(t[c]));
+	}
+	m1 = wave_max(m1);
+	if (t) mt = wave_max(mt);
+	float z1 = 0.f, zs = 0.f, zt = 0.f, sum_s = 0.f;
+	for (int c = lane; c < C; c += 64) {
+		const float v = to_f32<T>(s[c]);
+		z1 += expf(v - m1);
+		sum_s += v;
+		if (t) {
+			zs += expf((v - m1) * inv_tau);
+			zt += expf((to_f32<T>(t[c]) - mt) * inv_tau);
+		}
+	}
+	z1 = wave_sum(z1);
+	sum_s = wave_sum(sum_s);
+	const float lse1 = m1 + logf(z1);
+	float lse_s = 0.f, lse_t = 0.f;
+	if (t) {
+		zs = wave_sum(zs);
+		zt = wave_sum(zt);
+		lse_s = m1 * inv_tau + logf(zs);
+		lse_t = mt * inv_tau + logf(zt);
+	}
+	const int y = (int)labels[row];
+	const float invB = 1.f / (float)B;
+	const float w_ce = t ? (1.f - alpha) : 1.f;
+	float kl = 0.f;
+	for (int c = lane; c < C; c += 64) {
+		const float v = to_f32<T>(s[c]);
+		const float p = expf(v - lse1);
+		const float target = (c == y ? 1.f - ls : 0.f) + ls / (float)C;
+		float g = w_ce * (p - target) * invB;
+		if (t) {
+			const float lps = v * inv_tau - lse_s;
+			const float lpt = to_f32<T>(t[c]) * inv_tau - lse_t;
+			const float pt = expf(lpt);
+			kl += pt * (lpt - lps);
+			g += alpha * tau * (expf(lps) - pt) * invB;
+		}
+		dlogits[row * C + c] = from_f32<T>(g);
+	}
+	if (t) kl = wave_sum(kl);
+	if (lane == 0) {
+		const float nll = lse1 - to_f32<T>(s[y]);
+		const float smooth = lse1 - sum_s / (float)C;
+		float l = w_ce * ((1.f - ls) * nll + ls * smooth);
+		if (t) l += alpha * tau * tau * kl;
+		atomicAdd(loss, l * invB);
+	}
+}
+
+// ---- fused AdamW -----------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+	const uint8_t* __restrict__ wd_mask, bf16_t* __restrict__ p16, int64_t n, float lr, float b1, float b2, float eps, float wd, float inv_bc1,
+	float inv_sqrt_bc2, float gscale) {
+	for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+		const float gr = g[i] * gscale;
+		float pv = p[i];
+		const bool decay = wd_mask ? wd_mask[i] != 0 : true;
+		if (decay) pv *= 1.f - lr * wd;
+		const float mv = b1 * m[i] + (1.f - b1) * gr;
+		const float vv = b2 * v[i] + (1.f - b2) * gr * gr;
+		const float denom = sqrtf(vv) * inv_sqrt_bc2 + eps;
+		pv -= lr * inv_bc1 * mv / denom;
+		p[i] = pv;
+		m[i] = mv;
+		v[i] = vv;
+		if (p16) p16[i] = (bf16_t)pv;
+	}
+}
+
+}  // namespace
+
+#define DISPATCH_T(dtype, ...)                  \
+	do {                                        \
+		if ((dtype) == VITK_F32) {              \
+			using T = float;                    \
+			__VA_ARGS__;                        \
+		} else if ((dtype) == VITK_BF16) {      \
+			using T = bf16_t;                   \
+			__VA_ARGS__;                        \
+		} else                                  \
+			return VITK_ERR_DTYPE;              \
+	} while (0)
+
+extern "C" int vitk_cast(const void* src, void* dst, int64_t n, int src_dtype, int dst_dtype, void* stream) {
+	VITK_REQUIRE(src && dst, VITK_ERR_NULL);
+	VITK_REQUIRE(n >= 0, VITK_ERR_SHAPE);
+	hipStream_t st = (hipStream_t)stream;
+	if (src_dtype == VITK_F32 && dst_dtype == VITK_BF16) return launch_map2<float, float, bf16_t>(src, nullptr, dst, n, Ident{}, st);
+	if (src_dtype == VITK_BF16 && dst_dtype == VITK_F32) return launch_map2<bf16_t, float, float>(src, nullptr, dst, n, Ident{}, st);
+	if (src_dtype == VITK_F32 && dst_dtype == VITK_F32) return launch_map2<float, float, float>(src, nullptr, dst, n, Ident{}, st);
+	if (src_dtype == VITK_BF16 && dst_dtype == VITK_BF16) return launch_map2<bf16_t, float, bf16_t>(src, nullptr, dst, n, Ident{}, st);
+	return VITK_ERR_DTYPE;
+}
+
+extern "C" int vitk_act_fwd(const void* x, void* y, int64_t n, int act, int dtype, void* stream) {
+	VITK_REQUIRE(x && y, VITK_ERR_NULL);
+	VITK_REQUIRE(act >= 0 && act <= VITK_ACT_RELU6, VITK_ERR_UNSUPPORTED);
+	DISPATCH_T(dtype, return (launch_map2<T, T, T>(x, nullptr, y, n, ActF{act}, (hipStream_t)stream)));
+}
+
+extern "C" int vitk_act_bwd(const void* dy, const void* x, void* dx, int64_t n, int act, int dtype, void* stream) {
+	VITK_REQUIRE(dy && x && dx, VITK_ERR_NULL);
+	VITK_REQUIRE(act >= 0 && act <= VITK_ACT_RELU6, VITK_ERR_UNSUPPORTED);
+	DISPATCH_T(dtype, return (launch_map2<T, T, T>(dy, x, dx, n, ActB{act}, (hipStream_t)stream)));
+}
+
+extern "C" int vitk_dropout(const void* x, void* y, int64_t n, float p, uint64_t seed, int dtype, void* stream) {
+	VITK_REQUIRE(x && y, VITK_ERR_NULL);
+	VITK_REQUIRE(n >= 0 && p >= 0.f && p < 1.f, VITK_ERR_SHAPE);
+	DISPATCH_T(dtype, return (launch_map2<T, T, T>(x, nullptr, y, n, DropF{p, 1.f / (1.f - p), seed}, (hipStream_t)stream)));
+}
+
+extern "C" int vitk_colsum(const void* x, float* out, int64_t M, int64_t N, int64_t ld, int accumulate, int dtype, void* stream) {
+	VITK_REQUIRE(x && out, VITK_ERR_NULL);
+	VITK_REQUIRE(M > 0 && N > 0 && ld >= N, VITK_ERR_SHAPE);
+	hipStream_t st = (hipStream_t)stream;
+	if (!accumulate) {
+		hipError_t e = hipMemsetAsync(out, 0, (size_t)N * sizeof(float), st);
+		if (e != hipSuccess) return VITK_ERR_HIP - (int)e;
+	}
+	DISPATCH_T(dtype, return launch_colsum<T>(x, out, M, N, ld, st));
+}
+
+extern "C" int vitk_gated_act_fwd(const void* u, void* a, int64_t M, int64_t F, int64_t ld_u, int act, int dtype, void* stream) {
+	VITK_REQUIRE(u && a, VITK_ERR_NULL);
+	VITK_REQUIRE(M > 0 && F > 0 && ld_u >= 2 * F, VITK_ERR_SHAPE);
+	DISPATCH_T(dtype, {
+		hipLaunchKernelGGL((gated_fwd_kernel<T>), dim3(vitk_stream_grid(M * F, 256)), dim3(256), 0, (hipStream_t)stream, (const T*)u, (T*)a, M, F, ld_u, act);
+		VITK_CHECK_LAUNCH();
+		return VITK_OK;
+	});
+}
+
+extern "C" int vitk_gated_act_bwd(const void* da, const void* u, void* du, int64_t M, int64_t F, int64_t ld_u, int act, int dtype, void* stream) {
+	VITK_REQUIRE(da && u && du, VITK_ERR_NULL);
+	VITK_REQUIRE(M > 0 && F > 0 && ld_u >= 2 * F, VITK_ERR_SHAPE);
+	DISPATCH_T(dtype, {
+		hipLaunchKernelGGL((gated_bwd_kernel<T>), dim3(vitk_stream_grid(M * F, 256)), dim3(256), 0, (hipStream_t)stream, (const T*)da, (const T*)u, (T*)du, M, F, ld_u,
+			act);
+		VITK_CHECK_LAUNCH();
+		return VITK_OK;
+	});
+}
+
+extern "C" int vitk_scale_residual(const void* x, const void* res, const float* gamma, void* y, int64_t rows, int64_t d, int dtype, void* stream) {
+	VITK_REQUIRE(x && res && y, VITK_ERR_NULL);
+	VITK_REQUIRE(rows > 0 && d > 0, VITK_ERR_SHAPE);
+	DISPATCH_T(dtype, {
+		hipLaunchKernelGGL((scale_residual_kernel<T>), dim3(vitk_stream_grid(rows * d, 256)), dim3(256), 0, (hipStream_t)stream, (const T*)x, (const T*)res, gamma,
+			(T*)y, rows * d, d);
+		VITK_CHECK_LAUNCH();
+		return VITK_OK;
+	});
+}
+
+extern "C" int vitk_layerscale_bwd(const void* dy, const void* branch, const float* gamma, void* dbranch, float* dgamma, int64_t rows, int64_t d,
+	int dtype, void* stream) {
+	VITK_REQUIRE(dy && branch && gamma && dbranch && dgamma, VITK_ERR_NULL);
+	VITK_REQUIRE(rows > 0 && d > 0, VITK_ERR_SHAPE);
+	const unsigned gx = (unsigned)vitk_cdiv(d, 256);
+	const unsigned gy = (unsigned)std::min<int64_t>(rows, std::max<int64_t>(1, 1024 / gx));
+	DISPATCH_T(dtype, {
+		hipLaunchKernelGGL((layerscale_bwd_kernel<T>), dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, (const T*)dy, (const T*)branch, gamma, (T*)dbranch, dgamma,
+			rows, d);
+		VITK_CHECK_LAUNCH();
+		return VITK_OK;
+	});
+}
+
+extern "C" int vitk_cls_rows(void* x, const float* class_token, const float* pos_embed, int64_t B, int64_t tokens, int64_t d, int dtype, void* stream) {
+	VITK_REQUIRE(x && class_token && pos_embed, VITK_ERR_NULL);
+	VITK_REQUIRE(B > 0 && tokens > 0 && d > 0, VITK_ERR_SHAPE);
+	DISPATCH_T(dtype, {
+		hipLaunchKernelGGL((cls_rows_kernel<T>), dim3(vitk_stream_grid(B * d, 256)), dim3(256), 0, (hipStream_t)stream, (T*)x, class_token, pos_embed, B, tokens, d);
+		VITK_CHECK_LAUNCH();
+		return VITK_OK;
+	});
+}
+
+extern "C" int vitk_batch_sum(const void* dx, float* dpos, int64_t B, int64_t rows, int64_t d, int accumulate, int dtype, void* stream) {
+	VITK_REQUIRE(dx && dpos, VITK_ERR_NULL);
+	VITK_REQUIRE(B > 0 && rows > 0 && d > 0, VITK_ERR_SHAPE);
+	const int64_t per = rows * d;
+	const unsigned gx = (unsigned)vitk_cdiv(per, 256);
+	// split the batch so that the grid has ~2048 blocks
+	int64_t ysplit = std::max<int64_t>(1, std::min<int64_t>(B, 2048 / std::max<unsigned>(gx, 1u)));
+	const int64_t bchunk = vitk_cdiv(B, ysplit);
+	ysplit = vitk_cdiv(B, bchunk);
+	hipStream_t st = (hipStream_t)stream;
+	if (ysplit > 1 && !accumulate) {
+		hipError_t e = hipMemsetAsync(dpos, 0, (size_t)per * sizeof(float), st);
+		if (e != hipSuccess) return VITK_ERR_HIP - (int)e;
+	}
+	DISPATCH_T(dtype, {
+		hipLaunchKernelGGL((batch_sum_kernel<T>), dim3(gx, (unsigned)ysplit), dim3(256), 0, st, (const T*)dx, dpos, B, per, accumulate, bchunk);
+		VITK_CHECK_LAUNCH();
+		return VITK_OK;
+	});
+}
+
+static int patch_args_ok(int64_t B, int64_t C, int64_t HW, int64_t P) {
+	if (B <= 0 || C <= 0 || HW <= 0 || P <= 0 || HW % P != 0) return 0;
+	return 1;
+}
+
+extern "C" int vitk_patchify(const void* images, void* patches, int64_t B, int64_t C, int64_t HW, int64_t n_patch, int dtype, void* stream) {
+	VITK_REQUIRE(images && patches, VITK_ERR_NULL);
+	VITK_REQUIRE(patch_args_ok(B, C, HW, n_patch), VITK_ERR_SHAPE);
+	DISPATCH_T(dtype, {
+		hipLaunchKernelGGL((patchify_kernel<T, false>), dim3(vitk_stream_grid(B * C * HW * HW, 256)), dim3(256), 0, (hipStream_t)stream, (const T*)images,
+			(T*)patches, B, (int)C, (int)HW, (int)n_patch);
+		VITK_CHECK_LAUNCH();
+		return VITK_OK;
+	});
+}
+
+extern "C" int vitk_unpatchify(const void* patches, void* images, int64_t B, int64_t C, int64_t HW, int64_t n_patch, int dtype, void* stream) {
+	VITK_REQUIRE(images && patches, VITK_ERR_NULL);
+	VITK_REQUIRE(patch_args_ok(B, C, HW, n_patch), VITK_ERR_SHAPE);
+	DISPATCH_T(dtype, {
+		hipLaunchKernelGGL((patchify_kernel<T, true>), dim3(vitk_stream_grid(B * C * HW * HW, 256)), dim3(256), 0, (hipStream_t)stream, (const T*)patches, (T*)images,
+			B, (int)C, (int)HW, (int)n_patch);
+		VITK_CHECK_LAUNCH();
+		return VITK_OK;
+	});
+}
+
+extern "C" int vitk_drop_cls_rows(const void* x, void* out, int64_t B, int64_t tokens, int64_t d, int dtype, void* stream) {
+	VITK_REQUIRE(x && out, VITK_ERR_NULL);
+	VITK_REQUIRE(B > 0 && tokens > 1 && d > 0, VITK_ERR_SHAPE);
+	DISPATCH_T(dtype, {
+		hipLaunchKernelGGL((drop_cls_kernel<T>), dim3(vitk_stream_grid(B * (tokens - 1) * d, 256)), dim3(256), 0, (hipStream_t)stream, (const T*)x, (T*)out, B, tokens, d);
+		VITK_CHECK_LAUNCH();
+		return VITK_OK;
+	});
+}
+
+extern "C" int vitk_mean_pool_fwd(const void* x, void* y, int64_t B, int64_t S, int64_t d, int dtype, void* stream) {
+	VITK_REQUIRE(x && y, VITK_ERR_NULL);
+	VITK_REQUIRE(B > 0 && S > 0 && d > 0, VITK_ERR_SHAPE);
+	DISPATCH_T(dtype, {
+		hipLaunchKernelGGL((mean_pool_fwd_kernel<T>), dim3(vitk_stream_grid(B * d, 256)), dim3(256), 0, (hipStream_t)stream, (const T*)x, (T*)y, B, S, d);
+		VITK_CHECK_LAUNCH();
+		return VITK_OK;
+	});
+}
+
+extern "C" int vitk_mean_pool_bwd(const void* dy, void* dx, int64_t B, int64_t S, int64_t d, int dtype, void* stream) {
+	VITK_REQUIRE(dy && dx, VITK_ERR_NULL);
+	VITK_REQUIRE(B > 0 && S > 0 && d > 0, VITK_ERR_SHAPE);
+	DISPATCH_T(dtype, {
+		hipLaunchKernelGGL((mean_pool_bwd_kernel<T>), dim3(vitk_stream_grid(B * S * d, 256)), dim3(256), 0, (hipStream_t)stream, (const T*)dy, (T*)dx, B, S, d);
+		VITK_CHECK_LAUNCH();
+		return VITK_OK;
+	});
+}
+
+extern "C" int vitk_ce_kd_loss(const void* logits, const int64_t* labels, const void* teacher, float* loss, void* dlogits, int64_t B, int64_t C,
+	float label_smoothing, float alpha, float tau, int dtype, void* stream) {
+	VITK_REQUIRE(logits && labels && loss && dlogits, VITK_ERR_NULL);
+	VITK_REQUIRE(B > 0 && C > 0 && C < (1 << 24) && tau > 0.f, VITK_ERR_SHAPE);
+	if (teacher == nullptr) alpha = 0.f;
+	if (alpha == 0.f) teacher = nullptr;
+	DISPATCH_T(dtype, {
+		hipLaunchKernelGGL((ce_kd_kernel<T>), dim3((unsigned)vitk_cdiv(B, 4)), dim3(256), 0, (hipStream_t)stream, (const T*)logits, labels, (const T*)teacher, loss,
+			(T*)dlogits, B, (int)C, label_smoothing, alpha, tau);
+		VITK_CHECK_LAUNCH();
+		return VITK_OK;
+	});
+}
+
+extern "C" int vitk_adamw(float* p, const float* g, float* m, float* v, const uint8_t* wd_mask, void* p_bf16, int64_t n, float lr, float beta1,
+	float beta2, float eps, float weight_decay, int64_t step, float grad_scale, void* stream) {
+	VITK_REQUIRE(p && g && m && v, VITK_ERR_NULL);
+	VITK_REQUIRE(n > 0 && step >= 1, VITK_ERR_SHAPE);
+	const double bc1 = 1.0 - pow((double)beta1, (double)step);
+	const double bc2 = 1.0 - pow((double)beta2, (double)step);
+	hipLaunchKernelGGL(adamw_kernel, dim3(vitk_stream_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, wd_mask, (bf16_t*)p_bf16, n, lr, beta1, beta2, eps,
+		weight_decay, (float)(1.0 / bc1), (float)(1.0 / sqrt(bc2)), grad_scale);
+	VITK_CHECK_LAUNCH();
+	return VITK_OK;
+}

@@ -1,0 +1,283 @@
+// bf16 GEMM on the CDNA4 matrix cores (v_mfma_f32_16x16x32_bf16), float32 accumulation, fused epilogue.
+//
+//   C[M,N] = epilogue( sum_k A(m,k) B(n,k) )
+//
+// 128x128x64 tile per 256-thread workgroup (2x2 waves, 64x64 per wave = 4x4 MFMA tiles), two LDS
+// stages, one barrier per K-tile: the global loads of tile t+1 are issued into registers before the
+// MFMAs of tile t and written to the other LDS stage after them.
+//
+// Operand tiles in LDS (16 KiB each):
+//   K-major operand  (k contiguous in memory): image [128 rows][64 k] with 128-byte rows, the 16-byte
+//     chunk index XOR-ed with (row & 7) so that the ds_read_b128 of a fragment (16 rows x one chunk
+//     per lane group) is bank-conflict free.
+//   MN-major operand (m or n contiguous; the dgrad weight and both wgrad operands): image
+//     [64 k][128 cols] with 256-byte rows, read with the transposing ds_read_b64_tr_b16 so that no
+//     transposed copy of activations or weights is ever materialised in HBM; 32-byte units are
+//     XOR-ed with (k & 3) | ((k >> 3) & 1) << 2 to spread the 8 rows of a half-wave over the banks.
+//
+// The MFMA is issued as D = Wfrag x Xfrag so that a lane ends up with 4 consecutive n of one row m
+// (8-byte bf16 / 16-byte f32 stores and epilogue operand loads).
+#include "gemm_common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int TILE_BYTES = 128 * 64 * 2;  // 16 KiB, both layouts
+constexpr int STAGE_BYTES = 2 * TILE_BYTES;
+
+__device__ __forceinline__ int swz_k(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
+__device__ __forceinline__ int swz_mn(int krow, int chunk) {
+	const int unit = (chunk >> 1) ^ ((krow & 3) | (((krow >> 3) & 1) << 2));
+	return krow * 256 + (((unit << 1) | (chunk & 1)) << 4);
+}
+
+struct Frag {
+	bf16x8 v;
+};
+
+// fragment read: 16 rows (or cols) starting at `base`, k-step s (32 wide) of the staged 64-wide K tile
+template <int LAYOUT>
+__device__ __forceinline__ bf16x8 read_frag(const char* tile, int base, int s, int lane) {
+	if (LAYOUT == VITK_K_MAJOR) {
+		const int row = base + (lane & 15);
+		const int chunk = 4 * s + (lane >> 4);
+		return *reinterpret_cast<const bf16x8*>(tile + swz_k(row, chunk));
+	} else {
+		const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
+		const int krow = 32 * s + 8 * g + q;
+		const int col = base + 4 * p;
+		const int off = swz_mn(krow, col >> 3) + ((p & 1) << 3);
+		typedef s16x4 __attribute__((address_space(3))) * lds_ptr_t;
+		s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr_t)(tile + off));
+		s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr_t)(tile + off + 4 * 256));
+		union {
+			s16x4 h[2];
+			bf16x8 v;
+		} u;
+		u.h[0] = lo;
+		u.h[1] = hi;
+		return u.v;
+	}
+}
+
+// Global -> register staging of one operand tile: 4 chunks of 16 bytes per thread.
+// rows_total/cols_total bound the operand; OOB chunks read as zero (K tail) or a clamped row.
+template <int LAYOUT, bool PATCH>
+__device__ __forceinline__ void load_tile(const GemmDev& g, const bf16_t* __restrict__ base, int64_t ld, int64_t mn0, int64_t mn_total, int k0, int k_end,
+	uint4 (&regs)[4], int tid) {
+	if (LAYOUT == VITK_K_MAJOR) {
+		const int c = tid & 7;
+		const int k = k0 + 8 * c;
+#pragma unroll
+		for (int i = 0; i < 4; ++i) {
+			const int r = (tid >> 3) + 32 * i;
+			int64_t row = mn0 + r;
+			if (row >= mn_total) row = mn_total - 1;
+			uint4 v = make_uint4(0, 0, 0, 0);
+			if (k < k_end) {
+				const bf16_t* p = PATCH ? base + patch_offset(g, row, k) : base + row * ld + k;
+				v = *reinterpret_cast<const uint4*>(p);
+			}
+			regs[i] = v;
+		}
+	} else {
+		const int c = tid & 15;
+		const int64_t col = mn0 + 8 * c;
+#pragma unroll
+		for (int i = 0; i < 4; ++i) {
+			const int r = (tid >> 4) + 16 * i;
+			const int k = k0 + r;
+			uint4 v = make_uint4(0, 0, 0, 0);
+			if (k < k_end && col < mn_total) v = *reinterpret_cast<const uint4*>(base + (int64_t)k * ld + col);
+			regs[i] = v;
+		}
+	}
+}
+
+template <int LAYOUT>
+__device__ __forceinline__ void store_tile(char* tile, const uint4 (&regs)[4], int tid) {
+	if (LAYOUT == VITK_K_MAJOR) {
+		const int c = tid & 7;
+#pragma unroll
+		for (int i = 0; i < 4; ++i) {
+			const int r = (tid >> 3) + 32 * i;
+			*reinterpret_cast<uint4*>(tile + swz_k(r, c)) = regs[i];
+		}
+	} else {
+		const int c = tid & 15;
+#pragma unroll
+		for (int i = 0; i < 4; ++i) {
+			const int r = (tid >> 4) + 16 * i;
+			*reinterpret_cast<uint4*>(tile + swz_mn(r, c)) = regs[i];
+		}
+	}
+}
+
+struct BfArgs {
+	GemmDev g;
+	int tiles_m, tiles_n, splits, k_per_split;  // k_per_split is a multiple of BK
+	int vec4;                                    // epilogue may use 4-wide accesses
+};
+
+template <int ALAYOUT, int BLAYOUT, bool PATCH, typename TOUT>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(BfArgs a) {
+	extern __shared__ __attribute__((aligned(16))) char smem[];
+	const GemmDev& g = a.g;
+	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+
+	// XCD-aware, bijective remap of the linear workgroup id, then grouped (8 tile-rows) raster so that
+	// the workgroups sharing an XCD's L2 work on neighbouring tiles.
+	const int nwg = a.tiles_m * a.tiles_n;
+	int wg = blockIdx.x;
+	{
+		const int q = nwg >> 3, r = nwg & 7, xcd = wg & 7, idx = wg >> 3;
+		wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+	}
+	constexpr int GM = 8;
+	const int per_group = GM * a.tiles_n;
+	const int group = wg / per_group;
+	const int first_m = group * GM;
+	const int gsz = min(a.tiles_m - first_m, GM);
+	const int tm = first_m + (wg % per_group) % gsz;
+	const int tn = (wg % per_group) / gsz;
+	const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
+
+	const int k_begin = blockIdx.y * a.k_per_split;
+	const int k_end = min((int)g.K, k_begin + a.k_per_split);
+	const int nt = (k_end - k_begin + BK - 1) / BK;
+
+	const bf16_t* A = reinterpret_cast<const bf16_t*>(g.A);
+	const bf16_t* B = reinterpret_cast<const bf16_t*>(g.B);
+
+	f32x4 acc[4][4];
+#pragma unroll
+	for (int i = 0; i < 4; ++i)
+#pragma unroll
+		for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+	uint4 ra[4], rb[4];
+	load_tile<ALAYOUT, PATCH>(g, A, g.lda, m0, g.M, k_begin, k_end, ra, tid);
+	load_tile<BLAYOUT, false>(g, B, g.ldb, n0, g.N, k_begin, k_end, rb, tid);
+	store_tile<ALAYOUT>(smem, ra, tid);
+	store_tile<BLAYOUT>(smem + TILE_BYTES, rb, tid);
+	__syncthreads();
+
+	for (int t = 0; t < nt; ++t) {
+		const char* sa = smem + (t & 1) * STAGE_BYTES;
+		const char* sb = sa + TILE_BYTES;
+		const bool more = (t + 1 < nt);
+		if (more) {
+			const int k0 = k_begin + (t + 1) * BK;
+			load_tile<ALAYOUT, PATCH>(g, A, g.lda, m0, g.M, k0, k_end, ra, tid);
+			load_tile<BLAYOUT, false>(g, B, g.ldb, n0, g.N, k0, k_end, rb, tid);
+		}
+#pragma unroll
+		for (int s = 0; s < 2; ++s) {
+			bf16x8 xf[4], wf[4];
+#pragma unroll
+			for (int i = 0; i < 4; ++i) xf[i] = read_frag<ALAYOUT>(sa, wm + 16 * i, s, lane);
+#pragma unroll
+			for (int j = 0; j < 4; ++j) wf[j] = read_frag<BLAYOUT>(sb, wn + 16 * j, s, lane);
+#pragma unroll
+			for (int i = 0; i < 4; ++i)
+#pragma unroll
+				for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], acc[i][j], 0, 0, 0);
+		}
+		if (more) {
+			char* da = smem + ((t + 1) & 1) * STAGE_BYTES;
+			store_tile<ALAYOUT>(da, ra, tid);
+			store_tile<BLAYOUT>(da + TILE_BYTES, rb, tid);
+		}
+		__syncthreads();
+	}
+
+	// acc[i][j][r]: m = m0 + wm + 16 i + (lane & 15), n = n0 + wn + 16 j + 4 (lane >> 4) + r
+#pragma unroll
+	for (int i = 0; i < 4; ++i) {
+		const int64_t m = m0 + wm + 16 * i + (lane & 15);
+		if (m >= g.M) continue;
+#pragma unroll
+		for (int j = 0; j < 4; ++j) {
+			const int64_t nb = n0 + wn + 16 * j + 4 * (lane >> 4);
+			if (nb >= g.N) continue;
+			if (a.splits > 1) {
+				float* c = reinterpret_cast<float*>(g.C) + m * g.ldc + nb;
+#pragma unroll
+				for (int r = 0; r < 4; ++r)
+					if (nb + r < g.N) atomicAdd(c + r, acc[i][j][r]);
+			} else if (a.vec4 && nb + 3 < g.N) {
+				const float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+				epi_store4<bf16_t, TOUT>(g, m, nb, v);
+			} else {
+#pragma unroll
+				for (int r = 0; r < 4; ++r)
+					if (nb + r < g.N) epi_store1<bf16_t, TOUT>(g, m, nb + r, acc[i][j][r]);
+			}
+		}
+	}
+}
+
+template <int AL, int BL, bool PATCH>
+int launch(const BfArgs& a, int out_dtype, dim3 grid, hipStream_t st) {
+	const size_t lds = 2 * STAGE_BYTES;
+	if (out_dtype == VITK_BF16)
+		hipLaunchKernelGGL((gemm_bf16_kernel<AL, BL, PATCH, bf16_t>), grid, dim3(256), lds, st, a);
+	else
+		hipLaunchKernelGGL((gemm_bf16_kernel<AL, BL, PATCH, float>), grid, dim3(256), lds, st, a);
+	VITK_CHECK_LAUNCH();
+	return VITK_OK;
+}
+
+}  // namespace
+
+bool vitk_gemm_bf16_ok(const vitk_gemm_desc& d) {
+	if (d.in_dtype != VITK_BF16) return false;
+	if (d.K % 8 != 0) return false;
+	if (!vitk_aligned(d.A, 16) || !vitk_aligned(d.B, 16)) return false;
+	if (d.patch_grid > 0) {
+		const int p = d.img_hw / d.patch_grid;
+		if (p % 8 != 0 || d.a_layout != VITK_K_MAJOR) return false;
+	} else {
+		if (d.lda % 8 != 0) return false;
+		if (d.a_layout == VITK_MN_MAJOR && d.M % 8 != 0) return false;
+	}
+	if (d.ldb % 8 != 0) return false;
+	if (d.b_layout == VITK_MN_MAJOR && d.N % 8 != 0) return false;
+	// tiny problems: the generic kernel's 64x64 tiles waste less
+	if (d.M * d.N < 64 * 64 || d.K < 32) return false;
+	if (vitk_cdiv(d.M, BM) * vitk_cdiv(d.N, BN) > (1ll << 30)) return false;
+	return true;
+}
+
+int vitk_gemm_bf16(const vitk_gemm_desc& d, hipStream_t st) {
+	BfArgs a{};
+	a.g = make_gemm_dev(d);
+	a.tiles_m = (int)vitk_cdiv(d.M, BM);
+	a.tiles_n = (int)vitk_cdiv(d.N, BN);
+	const int64_t tiles = (int64_t)a.tiles_m * a.tiles_n;
+	const int64_t ktiles = vitk_cdiv(d.K, BK);
+	// split-K only for the plain float32-output form (weight gradients): few output tiles, long K
+	a.splits = 1;
+	if (d.out_dtype == VITK_F32 && d.epilogue == VITK_EPI_NONE && d.bias == nullptr && d.tokens_per_image == 0 && tiles < 384 && ktiles >= 16) {
+		int64_t s = std::min<int64_t>(vitk_cdiv(768, tiles), ktiles / 8);
+		a.splits = (int)std::max<int64_t>(1, std::min<int64_t>(s, 64));
+	}
+	const int64_t kt_per = vitk_cdiv(ktiles, a.splits);
+	a.k_per_split = (int)(kt_per * BK);
+	a.splits = (int)vitk_cdiv(ktiles, kt_per);
+	auto al16 = [](const void* p) { return p == nullptr || vitk_aligned(p, 16); };
+	a.vec4 = (d.N % 4 == 0) && (d.ldc % 4 == 0) && (d.ld_aux % 4 == 0) && (d.ld_out2 % 4 == 0) && al16(d.C) && al16(d.bias) && al16(d.gamma) && al16(d.pos) &&
+		al16(d.aux) && al16(d.out2);
+	if (a.splits > 1 && !d.accumulate) {
+		hipError_t e = hipMemset2DAsync(d.C, (size_t)d.ldc * sizeof(float), 0, (size_t)d.N * sizeof(float), (size_t)d.M, st);
+		if (e != hipSuccess) return VITK_ERR_HIP - (int)e;
+	}
+	dim3 grid((unsigned)tiles, (unsigned)a.splits);
+	const bool patch = d.patch_grid > 0;
+	if (patch) return launch<VITK_K_MAJOR, VITK_K_MAJOR, true>(a, d.out_dtype, grid, st);
+	if (d.a_layout == VITK_K_MAJOR && d.b_layout == VITK_K_MAJOR) return launch<VITK_K_MAJOR, VITK_K_MAJOR, false>(a, d.out_dtype, grid, st);
+	if (d.a_layout == VITK_K_MAJOR && d.b_layout == VITK_MN_MAJOR) return launch<VITK_K_MAJOR, VITK_MN_MAJOR, false>(a, d.out_dtype, grid, st);
+	if (d.a_layout == VITK_MN_MAJOR && d.b_layout == VITK_MN_MAJOR) return launch<VITK_MN_MAJOR, VITK_MN_MAJOR, false>(a, d.out_dtype, grid, st);
+	return launch<VITK_MN_MAJOR, VITK_K_MAJOR, false>(a, d.out_dtype, grid, st);
+}

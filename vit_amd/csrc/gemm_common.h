@@ -1,0 +1,128 @@
+// Device-side GEMM descriptor and the fused epilogue shared by the generic (float32-MFMA) and the
+// bf16-MFMA GEMM kernels.
+#pragma once
+
+#include "vitk_common.h"
+
+struct GemmDev {
+	const void* A;
+	const void* B;
+	void* C;
+	int64_t M, N, K;
+	int64_t lda, ldb, ldc;
+	int a_layout, b_layout;
+	int epilogue, act, accumulate;
+	int patch_grid, img_c, img_hw, patch_px;  // patch_px = img_hw / patch_grid
+	int tpi;                                  // tokens_per_image
+	const float* bias;
+	const float* gamma;
+	const float* pos;
+	const void* aux;
+	int64_t ld_aux;
+	void* out2;
+	int64_t ld_out2;
+};
+
+static inline GemmDev make_gemm_dev(const vitk_gemm_desc& d) {
+	GemmDev g{};
+	g.A = d.A; g.B = d.B; g.C = d.C;
+	g.M = d.M; g.N = d.N; g.K = d.K;
+	g.lda = d.lda; g.ldb = d.ldb; g.ldc = d.ldc;
+	g.a_layout = d.a_layout; g.b_layout = d.b_layout;
+	g.epilogue = d.epilogue; g.act = d.act; g.accumulate = d.accumulate;
+	g.patch_grid = d.patch_grid; g.img_c = d.img_c; g.img_hw = d.img_hw;
+	g.patch_px = d.patch_grid > 0 ? d.img_hw / d.patch_grid : 0;
+	g.tpi = d.tokens_per_image;
+	g.bias = d.bias; g.gamma = d.gamma; g.pos = d.pos;
+	g.aux = d.aux; g.ld_aux = d.ld_aux; g.out2 = d.out2; g.ld_out2 = d.ld_out2;
+	return g;
+}
+
+// Element offset of A(m,k) inside the NCHW image batch (im2col-free patch gather; layers/embeddings.py:12-16).
+__device__ __forceinline__ int64_t patch_offset(const GemmDev& g, int64_t m, int k) {
+	const int P = g.patch_grid, p = g.patch_px, hw = g.img_hw;
+	const int P2 = P * P;
+	const int64_t b = m / P2;
+	const int t = (int)(m - b * P2);
+	const int py = t / P, px = t - py * P;
+	const int pp = p * p;
+	const int c = k / pp, rem = k - c * pp;
+	const int i = rem / p, j = rem - i * p;
+	return ((b * g.img_c + c) * hw + (py * p + i)) * (int64_t)hw + (px * p + j);
+}
+
+__device__ __forceinline__ int64_t out_row(const GemmDev& g, int64_t m) { return g.tpi > 0 ? m + m / g.tpi + 1 : m; }
+
+// Epilogue for ONE element.
+template <typename TIN, typename TOUT>
+__device__ __forceinline__ void epi_store1(const GemmDev& g, int64_t m, int64_t n, float acc) {
+	float v = acc;
+	if (g.bias) v += g.bias[n];
+	if (g.tpi > 0 && g.pos) v += g.pos[(1 + m % g.tpi) * g.N + n];
+	const int64_t r = out_row(g, m);
+	if (g.epilogue == VITK_EPI_ACT) {
+		if (g.out2) reinterpret_cast<TOUT*>(g.out2)[r * g.ld_out2 + n] = from_f32<TOUT>(v);
+		// the activation sees the pre-activation as it is stored (rounded to the output type)
+		v = act_apply(g.out2 ? round_to<TOUT>(v) : v, g.act);
+	} else if (g.epilogue == VITK_EPI_RESIDUAL) {
+		const float res = to_f32<TIN>(reinterpret_cast<const TIN*>(g.aux)[r * g.ld_aux + n]);
+		v = res + (g.gamma ? g.gamma[n] : 1.f) * v;
+	} else if (g.epilogue == VITK_EPI_ACTGRAD) {
+		const float u = to_f32<TIN>(reinterpret_cast<const TIN*>(g.aux)[r * g.ld_aux + n]);
+		v = v * act_deriv(u, g.act);
+	}
+	TOUT* c = reinterpret_cast<TOUT*>(g.C) + r * g.ldc + n;
+	if (g.accumulate) v += to_f32<TOUT>(*c);
+	*c = from_f32<TOUT>(v);
+}
+
+// Epilogue for FOUR consecutive columns n0..n0+3 of row m (all in range, 8/16-byte aligned accesses).
+template <typename TIN, typename TOUT>
+__device__ __forceinline__ void epi_store4(const GemmDev& g, int64_t m, int64_t n0, const float (&acc)[4]) {
+	float v[4] = {acc[0], acc[1], acc[2], acc[3]};
+	if (g.bias) {
+		float b[4];
+		load_vec<float, 4>(g.bias + n0, b);
+#pragma unroll
+		for (int j = 0; j < 4; ++j) v[j] += b[j];
+	}
+	if (g.tpi > 0 && g.pos) {
+		float p[4];
+		load_vec<float, 4>(g.pos + (1 + m % g.tpi) * g.N + n0, p);
+#pragma unroll
+		for (int j = 0; j < 4; ++j) v[j] += p[j];
+	}
+	const int64_t r = out_row(g, m);
+	if (g.epilogue == VITK_EPI_ACT) {
+		if (g.out2) {
+			store_vec<TOUT, 4>(reinterpret_cast<TOUT*>(g.out2) + r * g.ld_out2 + n0, v);
+#pragma unroll
+			for (int j = 0; j < 4; ++j) v[j] = round_to<TOUT>(v[j]);
+		}
+#pragma unroll
+		for (int j = 0; j < 4; ++j) v[j] = act_apply(v[j], g.act);
+	} else if (g.epilogue == VITK_EPI_RESIDUAL) {
+		float res[4], gm[4] = {1.f, 1.f, 1.f, 1.f};
+		load_vec<TIN, 4>(reinterpret_cast<const TIN*>(g.aux) + r * g.ld_aux + n0, res);
+		if (g.gamma) load_vec<float, 4>(g.gamma + n0, gm);
+#pragma unroll
+		for (int j = 0; j < 4; ++j) v[j] = res[j] + gm[j] * v[j];
+	} else if (g.epilogue == VITK_EPI_ACTGRAD) {
+		float u[4];
+		load_vec<TIN, 4>(reinterpret_cast<const TIN*>(g.aux) + r * g.ld_aux + n0, u);
+#pragma unroll
+		for (int j = 0; j < 4; ++j) v[j] *= act_deriv(u[j], g.act);
+	}
+	TOUT* c = reinterpret_cast<TOUT*>(g.C) + r * g.ldc + n0;
+	if (g.accumulate) {
+		float o[4];
+		load_vec<TOUT, 4>(c, o);
+#pragma unroll
+		for (int j = 0; j < 4; ++j) v[j] += o[j];
+	}
+	store_vec<TOUT, 4>(c, v);
+}
+
+int vitk_gemm_generic(const vitk_gemm_desc& d, hipStream_t st);
+int vitk_gemm_bf16(const vitk_gemm_desc& d, hipStream_t st);  // returns VITK_ERR_UNSUPPORTED if the shape does not qualify
+bool vitk_gemm_bf16_ok(const vitk_gemm_desc& d);

@@ -1,0 +1,120 @@
+// Generic GEMM: any strides, any alignment, float32 or bfloat16 operands, float32 accumulation on the
+// exact-f32 matrix instruction v_mfma_f32_32x32x2_f32 (a k-ordered fmaf chain, bit-for-bit).
+// This is the float32 parity path and the path for bf16 shapes the bf16-MFMA kernel cannot take
+// (unaligned rows, tiny K / N).  64x64 output tile per 256-thread workgroup, each of the 4 waves
+// owns a 32x32 quadrant; operands are staged through LDS as float32 [k][m] / [k][n] so that both
+// fragment reads are 32 consecutive words (conflict-free ds_read_b32).
+#include "gemm_common.h"
+
+namespace {
+
+constexpr int BM = 64, BN = 64, BK = 32, LDS_LD = 65;
+
+template <typename TIN>
+__device__ __forceinline__ float load_a(const GemmDev& g, int64_t m, int k) {
+	const TIN* A = reinterpret_cast<const TIN*>(g.A);
+	if (g.patch_grid > 0) return to_f32<TIN>(A[patch_offset(g, m, k)]);
+	return to_f32<TIN>(g.a_layout == VITK_K_MAJOR ? A[m * g.lda + k] : A[(int64_t)k * g.lda + m]);
+}
+template <typename TIN>
+__device__ __forceinline__ float load_b(const GemmDev& g, int64_t n, int k) {
+	const TIN* B = reinterpret_cast<const TIN*>(g.B);
+	return to_f32<TIN>(g.b_layout == VITK_K_MAJOR ? B[n * g.ldb + k] : B[(int64_t)k * g.ldb + n]);
+}
+
+template <typename TIN, typename TOUT>
+__global__ __launch_bounds__(256) void gemm_generic_kernel(GemmDev g) {
+	__shared__ float As[BK * LDS_LD];
+	__shared__ float Bs[BK * LDS_LD];
+	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	const int64_t m0 = (int64_t)blockIdx.y * BM, n0 = (int64_t)blockIdx.x * BN;
+	const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
+	f32x16 acc = {};
+	const int K = (int)g.K;
+	// thread -> element of the 64 x 32 staging tile: consecutive threads follow the contiguous index
+	const bool a_kmajor = (g.a_layout == VITK_K_MAJOR) || g.patch_grid > 0;
+	const bool b_kmajor = (g.b_layout == VITK_K_MAJOR);
+	for (int k0 = 0; k0 < K; k0 += BK) {
+#pragma unroll
+		for (int i = 0; i < 8; ++i) {
+			int mm, kk;
+			if (a_kmajor) { kk = tid & 31; mm = (tid >> 5) + 8 * i; } else { mm = tid & 63; kk = (tid >> 6) + 4 * i; }
+			const int64_t m = m0 + mm;
+			float v = 0.f;
+			if (m < g.M && k0 + kk < K) v = load_a<TIN>(g, m, k0 + kk);
+			As[kk * LDS_LD + mm] = v;
+			int nn, kb;
+			if (b_kmajor) { kb = tid & 31; nn = (tid >> 5) + 8 * i; } else { nn = tid & 63; kb = (tid >> 6) + 4 * i; }
+			const int64_t n = n0 + nn;
+			float w = 0.f;
+			if (n < g.N && k0 + kb < K) w = load_b<TIN>(g, n, k0 + kb);
+			Bs[kb * LDS_LD + nn] = w;
+		}
+		__syncthreads();
+#pragma unroll
+		for (int ks = 0; ks < BK; ks += 2) {
+			const float a = As[(ks + (lane >> 5)) * LDS_LD + wm + (lane & 31)];
+			const float b = Bs[(ks + (lane >> 5)) * LDS_LD + wn + (lane & 31)];
+			acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+		}
+		__syncthreads();
+	}
+	// D layout: column (n) = lane & 31, row (m) = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+	const int64_t n = n0 + wn + (lane & 31);
+	if (n < g.N) {
+#pragma unroll
+		for (int r = 0; r < 16; ++r) {
+			const int64_t m = m0 + wm + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+			if (m < g.M) epi_store1<TIN, TOUT>(g, m, n, acc[r]);
+		}
+	}
+}
+
+}  // namespace
+
+int vitk_gemm_generic(const vitk_gemm_desc& d, hipStream_t st) {
+	GemmDev g = make_gemm_dev(d);
+	dim3 grid((unsigned)vitk_cdiv(d.N, BN), (unsigned)vitk_cdiv(d.M, BM));
+	VITK_REQUIRE(vitk_cdiv(d.M, BM) <= 65535, VITK_ERR_SHAPE);
+	if (d.in_dtype == VITK_F32 && d.out_dtype == VITK_F32)
+		hipLaunchKernelGGL((gemm_generic_kernel<float, float>), grid, dim3(256), 0, st, g);
+	else if (d.in_dtype == VITK_BF16 && d.out_dtype == VITK_BF16)
+		hipLaunchKernelGGL((gemm_generic_kernel<bf16_t, bf16_t>), grid, dim3(256), 0, st, g);
+	else if (d.in_dtype == VITK_BF16 && d.out_dtype == VITK_F32)
+		hipLaunchKernelGGL((gemm_generic_kernel<bf16_t, float>), grid, dim3(256), 0, st, g);
+	else
+		return VITK_ERR_DTYPE;
+	VITK_CHECK_LAUNCH();
+	return VITK_OK;
+}
+
+extern "C" int vitk_gemm(const vitk_gemm_desc* desc, void* stream) {
+	VITK_REQUIRE(desc != nullptr, VITK_ERR_NULL);
+	const vitk_gemm_desc& d = *desc;
+	VITK_REQUIRE(d.A && d.B && d.C, VITK_ERR_NULL);
+	VITK_REQUIRE(d.M > 0 && d.N > 0 && d.K > 0 && d.K < (1ll << 31) && d.N < (1ll << 31), VITK_ERR_SHAPE);
+	VITK_REQUIRE(d.a_layout == VITK_K_MAJOR || d.a_layout == VITK_MN_MAJOR, VITK_ERR_UNSUPPORTED);
+	VITK_REQUIRE(d.b_layout == VITK_K_MAJOR || d.b_layout == VITK_MN_MAJOR, VITK_ERR_UNSUPPORTED);
+	VITK_REQUIRE(d.epilogue >= VITK_EPI_NONE && d.epilogue <= VITK_EPI_ACTGRAD, VITK_ERR_UNSUPPORTED);
+	VITK_REQUIRE(d.act >= VITK_ACT_NONE && d.act <= VITK_ACT_RELU6, VITK_ERR_UNSUPPORTED);
+	VITK_REQUIRE(d.ldc >= d.N, VITK_ERR_SHAPE);
+	if (d.patch_grid > 0) {
+		VITK_REQUIRE(d.img_c > 0 && d.img_hw > 0 && d.img_hw % d.patch_grid == 0, VITK_ERR_SHAPE);
+		const int64_t p = d.img_hw / d.patch_grid;
+		VITK_REQUIRE(d.K == (int64_t)d.img_c * p * p, VITK_ERR_SHAPE);
+		VITK_REQUIRE(d.M % ((int64_t)d.patch_grid * d.patch_grid) == 0, VITK_ERR_SHAPE);
+	} else {
+		VITK_REQUIRE(d.lda >= (d.a_layout == VITK_K_MAJOR ? d.K : d.M), VITK_ERR_SHAPE);
+	}
+	VITK_REQUIRE(d.ldb >= (d.b_layout == VITK_K_MAJOR ? d.K : d.N), VITK_ERR_SHAPE);
+	if (d.tokens_per_image > 0) VITK_REQUIRE(d.M % d.tokens_per_image == 0, VITK_ERR_SHAPE);
+	if (d.epilogue == VITK_EPI_RESIDUAL || d.epilogue == VITK_EPI_ACTGRAD) VITK_REQUIRE(d.aux != nullptr && d.ld_aux >= d.N, VITK_ERR_NULL);
+	if (d.out2 != nullptr) VITK_REQUIRE(d.epilogue == VITK_EPI_ACT && d.ld_out2 >= d.N, VITK_ERR_UNSUPPORTED);
+	if (d.accumulate) VITK_REQUIRE(d.out_dtype == VITK_F32, VITK_ERR_UNSUPPORTED);
+	VITK_REQUIRE(d.in_dtype == VITK_F32 || d.in_dtype == VITK_BF16, VITK_ERR_DTYPE);
+	VITK_REQUIRE(d.out_dtype == VITK_F32 || d.out_dtype == VITK_BF16, VITK_ERR_DTYPE);
+	VITK_REQUIRE(!(d.in_dtype == VITK_F32 && d.out_dtype == VITK_BF16), VITK_ERR_DTYPE);
+	hipStream_t st = (hipStream_t)stream;
+	if (d.in_dtype == VITK_BF16 && vitk_gemm_bf16_ok(d)) return vitk_gemm_bf16(d, st);
+	return vitk_gemm_generic(d, st);
+}

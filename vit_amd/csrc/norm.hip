@@ -1,0 +1,283 @@
+// LayerNorm / RMSNorm forward and backward with optional fused residual add.
+//
+// Bandwidth-bound: one 64-lane wavefront owns one row, keeps it in registers (ITERS 16-byte
+// chunks per lane), and reduces with cross-lane shuffles.  Algorithmic HBM bytes per row:
+// forward 2*d*e (+ 2*d*e with the fused residual add), backward 3*d*e (+ d*e with dres).
+#include "vitk_common.h"
+
+namespace {
+
+template <typename T, int VEC, int ITERS, bool RMS>
+__global__ __launch_bounds__(256) void norm_fwd_kernel(const T* __restrict__ x, const T* __restrict__ res,
+	const float* __restrict__ gamma, const float* __restrict__ beta, T* __restrict__ y, T* sum_out,
+	float* __restrict__ mean_out, float* __restrict__ rstd_out, int64_t rows, int d, float eps, float offset) {
+	const int lane = threadIdx.x & 63;
+	const int wave = threadIdx.x >> 6;
+	const int64_t nwaves = (int64_t)gridDim.x * 4;
+	const int nchunk = d / VEC;
+	const float inv_d = 1.0f / (float)d;
+	for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += nwaves) {
+		const T* xr = x + row * d;
+		float v[ITERS][VEC];
+		float s = 0.f;
+#pragma unroll
+		for (int it = 0; it < ITERS; ++it) {
+			const int c = lane + it * 64;
+			if (c < nchunk) {
+				load_vec<T, VEC>(xr + c * VEC, v[it]);
+				if (res != nullptr) {
+					float r[VEC];
+					load_vec<T, VEC>(res + row * d + c * VEC, r);
+#pragma unroll
+					for (int j = 0; j < VEC; ++j) v[it][j] = round_to<T>(v[it][j] + r[j]);
+					store_vec<T, VEC>(sum_out + row * d + c * VEC, v[it]);
+				}
+#pragma unroll
+				for (int j = 0; j < VEC; ++j) s += RMS ? v[it][j] * v[it][j] : v[it][j];
+			} else {
+#pragma unroll
+				for (int j = 0; j < VEC; ++j) v[it][j] = 0.f;
+			}
+		}
+		s = wave_sum(s);
+		float mu = 0.f, rstd;
+		if (RMS) {
+			rstd = rsqrtf(s * inv_d + eps);
+		} else {
+			mu = s * inv_d;
+			float q = 0.f;
+#pragma unroll
+			for (int it = 0; it < ITERS; ++it) {
+				if (lane + it * 64 < nchunk) {
+#pragma unroll
+					for (int j = 0; j < VEC; ++j) {
+						const float t = v[it][j] - mu;
+						q += t * t;
+					}
+				}
+			}
+			q = wave_sum(q);
+			rstd = rsqrtf(q * inv_d + eps);
+		}
+		if (lane == 0) {
+			if (!RMS) mean_out[row] = mu;
+			rstd_out[row] = rstd;
+		}
+#pragma unroll
+		for (int it = 0; it < ITERS; ++it) {
+			const int c = lane + it * 64;
+			if (c < nchunk) {
+				float g[VEC], o[VEC];
+				load_vec<float, VEC>(gamma + c * VEC, g);
+				if (RMS) {
+#pragma unroll
+					for (int j = 0; j < VEC; ++j) o[j] = v[it][j] * rstd * (offset + g[j]);
+				} else {
+					float b[VEC];
+					load_vec<float, VEC>(beta + c * VEC, b);
+#pragma unroll
+					for (int j = 0; j < VEC; ++j) o[j] = (v[it][j] - mu) * rstd * g[j] + b[j];
+				}
+				store_vec<T, VEC>(y + row * d + c * VEC, o);
+			}
+		}
+	}
+}
+
+template <typename T, int VEC, int ITERS, bool RMS>
+__global__ __launch_bounds__(256) void norm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+	const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ rstd_in,
+	const T* __restrict__ dres, T* __restrict__ dx, float* dgamma, float* dbeta, int64_t rows, int d, float offset) {
+	extern __shared__ __attribute__((aligned(16))) float red[];  // [2][d]
+	const int lane = threadIdx.x & 63;
+	const int wave = threadIdx.x >> 6;
+	const int64_t nwaves = (int64_t)gridDim.x * 4;
+	const int nchunk = d / VEC;
+	const float inv_d = 1.0f / (float)d;
+	for (int i = threadIdx.x; i < 2 * d; i += 256) red[i] = 0.f;
+	__syncthreads();
+
+	float gsc[ITERS][VEC];  // gamma (+offset) for this lane's columns
+	float accg[ITERS][VEC], accb[ITERS][VEC];
+#pragma unroll
+	for (int it = 0; it < ITERS; ++it) {
+		const int c = lane + it * 64;
+#pragma unroll
+		for (int j = 0; j < VEC; ++j) {
+			accg[it][j] = 0.f;
+			accb[it][j] = 0.f;
+			gsc[it][j] = 0.f;
+		}
+		if (c < nchunk) {
+			load_vec<float, VEC>(gamma + c * VEC, gsc[it]);
+			if (RMS) {
+#pragma unroll
+				for (int j = 0; j < VEC; ++j) gsc[it][j] += offset;
+			}
+		}
+	}
+	for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += nwaves) {
+		const float mu = RMS ? 0.f : mean[row];
+		const float rs = rstd_in[row];
+		float xh[ITERS][VEC], g[ITERS][VEC];
+		float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+		for (int it = 0; it < ITERS; ++it) {
+			const int c = lane + it * 64;
+			if (c < nchunk) {
+				float dyv[VEC];
+				load_vec<T, VEC>(x + row * d + c * VEC, xh[it]);
+				load_vec<T, VEC>(dy + row * d + c * VEC, dyv);
+#pragma unroll
+				for (int j = 0; j < VEC; ++j) {
+					xh[it][j] = (xh[it][j] - mu) * rs;
+					g[it][j] = dyv[j] * gsc[it][j];
+					s1 += g[it][j];
+					s2 += g[it][j] * xh[it][j];
+					accg[it][j] += dyv[j] * xh[it][j];
+					accb[it][j] += dyv[j];
+				}
+			} else {
+#pragma unroll
+				for (int j = 0; j < VEC; ++j) {
+					xh[it][j] = 0.f;
+					g[it][j] = 0.f;
+				}
+			}
+		}
+		s2 = wave_sum(s2) * inv_d;
+		s1 = RMS ? 0.f : wave_sum(s1) * inv_d;
+#pragma unroll
+		for (int it = 0; it < ITERS; ++it) {
+			const int c = lane + it * 64;
+			if (c < nchunk) {
+				float o[VEC];
+#pragma unroll
+				for (int j = 0; j < VEC; ++j) o[j] = (g[it][j] - s1 - xh[it][j] * s2) * rs;
+				if (dres != nullptr) {
+					float r[VEC];
+					load_vec<T, VEC>(dres + row * d + c * VEC, r);
+#pragma unroll
+					for (int j = 0; j < VEC; ++j) o[j] += r[j];
+				}
+				store_vec<T, VEC>(dx + row * d + c * VEC, o);
+			}
+		}
+	}
+	// column sums: waves of the block combine in LDS, then one float atomic per column per block
+#pragma unroll
+	for (int it = 0; it < ITERS; ++it) {
+		const int c = lane + it * 64;
+		if (c < nchunk) {
+#pragma unroll
+			for (int j = 0; j < VEC; ++j) {
+				atomicAdd(&red[c * VEC + j], accg[it][j]);
+				if (!RMS) atomicAdd(&red[d + c * VEC + j], accb[it][j]);
+			}
+		}
+	}
+	__syncthreads();
+	for (int i = threadIdx.x; i < d; i += 256) {
+		atomicAdd(&dgamma[i], red[i]);
+		if (!RMS) atomicAdd(&dbeta[i], red[d + i]);
+	}
+}
+
+struct NormArgs {
+	const void *x, *res, *dy, *dres;
+	const float *gamma, *beta, *mean_in, *rstd_in;
+	void *y, *sum_out, *dx;
+	float *mean, *rstd, *dgamma, *dbeta;
+	int64_t rows;
+	int d;
+	float eps, offset;
+};
+
+template <typename T, int VEC, int ITERS, bool RMS>
+int launch_fwd(const NormArgs& a, hipStream_t st) {
+	int grid = (int)std::min<int64_t>(vitk_cdiv(a.rows, 4), 8192);
+	hipLaunchKernelGGL((norm_fwd_kernel<T, VEC, ITERS, RMS>), dim3(grid), dim3(256), 0, st, (const T*)a.x, (const T*)a.res, a.gamma, a.beta,
+		(T*)a.y, (T*)a.sum_out, a.mean, a.rstd, a.rows, a.d, a.eps, a.offset);
+	VITK_CHECK_LAUNCH();
+	return VITK_OK;
+}
+template <typename T, int VEC, int ITERS, bool RMS>
+int launch_bwd(const NormArgs& a, hipStream_t st) {
+	int grid = (int)std::min<int64_t>(vitk_cdiv(a.rows, 4), 1024);
+	size_t lds = (size_t)2 * a.d * sizeof(float);
+	hipLaunchKernelGGL((norm_bwd_kernel<T, VEC, ITERS, RMS>), dim3(grid), dim3(256), lds, st, (const T*)a.dy, (const T*)a.x, a.gamma, a.mean_in,
+		a.rstd_in, (const T*)a.dres, (T*)a.dx, a.dgamma, a.dbeta, a.rows, a.d, a.offset);
+	VITK_CHECK_LAUNCH();
+	return VITK_OK;
+}
+
+template <typename T, bool RMS, bool FWD>
+int dispatch(const NormArgs& a, bool vec_ok, hipStream_t st) {
+	constexpr int V = VecOf<T>::N;
+#define NORM_GO(VEC_, IT_) return FWD ? launch_fwd<T, VEC_, IT_, RMS>(a, st) : launch_bwd<T, VEC_, IT_, RMS>(a, st)
+	if (vec_ok && a.d % V == 0) {
+		const int iters = (int)vitk_cdiv(a.d / V, 64);
+		if (iters <= 1) NORM_GO(V, 1);
+		if (iters <= 2) NORM_GO(V, 2);
+		if (iters <= 4) NORM_GO(V, 4);
+		if (iters <= 8) NORM_GO(V, 8);
+		return VITK_ERR_SHAPE;
+	}
+	const int iters = (int)vitk_cdiv(a.d, 64);
+	if (iters <= 1) NORM_GO(1, 1);
+	if (iters <= 4) NORM_GO(1, 4);
+	if (iters <= 16) NORM_GO(1, 16);
+	return VITK_ERR_SHAPE;
+#undef NORM_GO
+}
+
+template <bool RMS, bool FWD>
+int run(const NormArgs& a, int dtype, hipStream_t st) {
+	VITK_REQUIRE(a.rows > 0 && a.d > 0 && a.d <= 8192, VITK_ERR_SHAPE);
+	bool vec_ok = vitk_aligned(a.x, 16) && vitk_aligned(a.gamma, 16) && (a.beta == nullptr || vitk_aligned(a.beta, 16)) &&
+		(a.res == nullptr || vitk_aligned(a.res, 16)) && (a.y == nullptr || vitk_aligned(a.y, 16)) && (a.sum_out == nullptr || vitk_aligned(a.sum_out, 16)) &&
+		(a.dy == nullptr || vitk_aligned(a.dy, 16)) && (a.dres == nullptr || vitk_aligned(a.dres, 16)) && (a.dx == nullptr || vitk_aligned(a.dx, 16));
+	if (dtype == VITK_F32) return dispatch<float, RMS, FWD>(a, vec_ok, st);
+	if (dtype == VITK_BF16) return dispatch<bf16_t, RMS, FWD>(a, vec_ok, st);
+	return VITK_ERR_DTYPE;
+}
+
+}  // namespace
+
+extern "C" int vitk_layernorm_fwd(const void* x, const void* res, const float* gamma, const float* beta, void* y, void* sum_out, float* mean,
+	float* rstd, int64_t rows, int64_t d, float eps, int dtype, void* stream) {
+	VITK_REQUIRE(x && gamma && beta && y && mean && rstd, VITK_ERR_NULL);
+	VITK_REQUIRE(res == nullptr || sum_out != nullptr, VITK_ERR_NULL);
+	NormArgs a{};
+	a.x = x; a.res = res; a.gamma = gamma; a.beta = beta; a.y = y; a.sum_out = sum_out; a.mean = mean; a.rstd = rstd;
+	a.rows = rows; a.d = (int)d; a.eps = eps; a.offset = 0.f;
+	return run<false, true>(a, dtype, (hipStream_t)stream);
+}
+
+extern "C" int vitk_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd, const void* dres,
+	void* dx, float* dgamma, float* dbeta, int64_t rows, int64_t d, int dtype, void* stream) {
+	VITK_REQUIRE(dy && x && gamma && mean && rstd && dx && dgamma && dbeta, VITK_ERR_NULL);
+	NormArgs a{};
+	a.dy = dy; a.x = x; a.gamma = gamma; a.mean_in = mean; a.rstd_in = rstd; a.dres = dres; a.dx = dx; a.dgamma = dgamma; a.dbeta = dbeta;
+	a.rows = rows; a.d = (int)d; a.offset = 0.f;
+	return run<false, false>(a, dtype, (hipStream_t)stream);
+}
+
+extern "C" int vitk_rmsnorm_fwd(const void* x, const void* res, const float* weight, void* y, void* sum_out, float* rstd, int64_t rows,
+	int64_t d, float eps, int unit_offset, int dtype, void* stream) {
+	VITK_REQUIRE(x && weight && y && rstd, VITK_ERR_NULL);
+	VITK_REQUIRE(res == nullptr || sum_out != nullptr, VITK_ERR_NULL);
+	NormArgs a{};
+	a.x = x; a.res = res; a.gamma = weight; a.y = y; a.sum_out = sum_out; a.rstd = rstd;
+	a.rows = rows; a.d = (int)d; a.eps = eps; a.offset = unit_offset ? 1.f : 0.f;
+	return run<true, true>(a, dtype, (hipStream_t)stream);
+}
+
+extern "C" int vitk_rmsnorm_bwd(const void* dy, const void* x, const float* weight, const float* rstd, const void* dres, void* dx,
+	float* dweight, int64_t rows, int64_t d, int unit_offset, int dtype, void* stream) {
+	VITK_REQUIRE(dy && x && weight && rstd && dx && dweight, VITK_ERR_NULL);
+	NormArgs a{};
+	a.dy = dy; a.x = x; a.gamma = weight; a.rstd_in = rstd; a.dres = dres; a.dx = dx; a.dgamma = dweight;
+	a.rows = rows; a.d = (int)d; a.offset = unit_offset ? 1.f : 0.f;
+	return run<true, false>(a, dtype, (hipStream_t)stream);
+}

@@ -1,0 +1,680 @@
+"""Tensor-level wrappers over the vitk C ABI and the autograd Functions built from them.
+
+Layout conventions: activations are row-major [rows, features] (any leading dims flattened),
+weights keep the reference's nn.Linear layout [out_features, in_features].  `compute dtype` is the
+dtype of the activations (float32 or bfloat16); weights are cast to it through a version-keyed
+cache, parameter gradients are produced in float32 and cast to the parameter dtype if needed.
+"""
+import math
+import weakref
+
+import torch
+
+from . import _lib as L
+
+
+# --------------------------------------------------------------------------------------------------
+# dtype plumbing
+# --------------------------------------------------------------------------------------------------
+
+def compute_dtype(x):
+	"""bfloat16 when the input is bfloat16 or bf16 autocast is active, else float32."""
+	if x.dtype == torch.bfloat16:
+		return torch.bfloat16
+	if torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16:
+		return torch.bfloat16
+	if x.dtype == torch.float32:
+		return torch.float32
+	raise TypeError(f"unsupported activation dtype {x.dtype}")
+
+
+def cast(t, dtype):
+	"""Contiguous copy of t in `dtype` through vitk_cast (no-op if already there)."""
+	if t.dtype == dtype and t.is_contiguous():
+		return t
+	if not t.is_contiguous():
+		t = t.contiguous()
+	if t.dtype == dtype:
+		return t
+	out = torch.empty(t.shape, dtype=dtype, device=t.device)
+	L.check(L.load().vitk_cast(L.ptr(t), L.ptr(out), t.numel(), L.dtype_code(t.dtype), L.dtype_code(dtype), L.stream()))
+	return out
+
+
+_cast_cache = {}  # id(param) -> (weakref(param), key, cast copy)
+
+
+def weight_as(w, dtype):
+	"""`w` in the compute dtype.  The cast of a parameter is cached until the parameter is modified
+	in place (optimizer step, load_state_dict), which bumps its version counter."""
+	if w.dtype == dtype and w.is_contiguous():
+		return w.detach()
+	key = (w._version, dtype, w.data_ptr())
+	hit = _cast_cache.get(id(w))
+	if hit is not None and hit[0]() is w and hit[1] == key:
+		return hit[2]
+	out = cast(w.detach(), dtype)
+	wid = id(w)
+	_cast_cache[wid] = (weakref.ref(w, lambda _r, wid=wid: _cast_cache.pop(wid, None)), key, out)
+	return out
+
+
+def f32(t):
+	"""float32 view/copy of a small parameter vector (norm weights, biases, LayerScale)."""
+	if t is None:
+		return None
+	return weight_as(t, torch.float32)
+
+
+def grad_as(g, like):
+	if g is None or like is None:
+		return None
+	return g if g.dtype == like.dtype else cast(g, like.dtype)
+
+
+# --------------------------------------------------------------------------------------------------
+# raw kernels
+# --------------------------------------------------------------------------------------------------
+
+def gemm(A, B, C, M, N, K, lda, ldb, ldc, a_layout=L.K_MAJOR, b_layout=L.K_MAJOR, bias=None, epilogue=L.EPI_NONE, act=L.ACT_NONE,
+		aux=None, ld_aux=0, out2=None, ld_out2=0, gamma=None, accumulate=False, patch=None, tokens_per_image=0, pos=None):
+	"""C[M,N] (+)= epilogue(sum_k A(m,k) B(n,k)); see include/vitk.h for the operand layouts."""
+	L.require_gpu(A, B, C)
+	d = L.GemmDesc()
+	d.A, d.B, d.C = A.data_ptr(), B.data_ptr(), C.data_ptr()
+	d.M, d.N, d.K = M, N, K
+	d.lda, d.ldb, d.ldc = lda, ldb, ldc
+	d.a_layout, d.b_layout = a_layout, b_layout
+	d.in_dtype, d.out_dtype = L.dtype_code(A.dtype), L.dtype_code(C.dtype)
+	assert B.dtype == A.dtype
+	d.epilogue, d.act, d.accumulate = epilogue, act, int(accumulate)
+	if patch is not None:
+		d.patch_grid, d.img_c, d.img_hw = patch
+	d.tokens_per_image = tokens_per_image
+	d.bias, d.gamma, d.pos = L.ptr(bias), L.ptr(gamma), L.ptr(pos)
+	d.aux, d.ld_aux = L.ptr(aux), ld_aux
+	d.out2, d.ld_out2 = L.ptr(out2), ld_out2
+	for t in (bias, gamma, pos):
+		assert t is None or (t.dtype == torch.float32 and t.is_contiguous())
+	assert aux is None or aux.dtype == A.dtype
+	assert out2 is None or out2.dtype == C.dtype
+	L.check(L.load().vitk_gemm(d, L.stream()))
+	return C
+
+
+def linear_fwd(x, w, bias=None, act=L.ACT_NONE, residual=None, gamma=None, save_pre=False, out_dtype=None):
+	"""y = epilogue(x @ w.T + bias).  x: [M, K] (row stride may exceed K), w: [N, K] contiguous.
+	Returns y, or (y, pre_activation) with save_pre."""
+	M, K = x.shape
+	N = w.shape[0]
+	assert w.shape[1] == K and x.stride(1) == 1 and w.is_contiguous()
+	y = torch.empty((M, N), dtype=out_dtype or x.dtype, device=x.device)
+	pre = torch.empty_like(y) if save_pre else None
+	if residual is not None:
+		assert residual.shape == (M, N) and residual.stride(1) == 1
+		gemm(x, w, y, M, N, K, x.stride(0), K, N, bias=bias, epilogue=L.EPI_RESIDUAL, aux=residual, ld_aux=residual.stride(0), gamma=gamma)
+	elif act != L.ACT_NONE:
+		gemm(x, w, y, M, N, K, x.stride(0), K, N, bias=bias, epilogue=L.EPI_ACT, act=act, out2=pre, ld_out2=N)
+	else:
+		gemm(x, w, y, M, N, K, x.stride(0), K, N, bias=bias)
+	return (y, pre) if save_pre else y
+
+
+def linear_dgrad(dy, w, act=L.ACT_NONE, pre=None, out=None):
+	"""dx = dy @ w, optionally multiplied by act'(pre) (pre = saved pre-activation of the layer that produced x)."""
+	M, N = dy.shape
+	K = w.shape[1]
+	assert w.shape[0] == N and dy.stride(1) == 1 and w.is_contiguous()
+	dx = out if out is not None else torch.empty((M, K), dtype=dy.dtype, device=dy.device)
+	# sum over n: A = dy (n contiguous), B(n'=k, k'=n) = w[n, k] -> MN-major with ldb = K
+	if pre is not None:
+		gemm(dy, w, dx, M, K, N, dy.stride(0), K, dx.stride(0), b_layout=L.MN_MAJOR, epilogue=L.EPI_ACTGRAD, act=act, aux=pre, ld_aux=pre.stride(0))
+	else:
+		gemm(dy, w, dx, M, K, N, dy.stride(0), K, dx.stride(0), b_layout=L.MN_MAJOR)
+	return dx
+
+
+def linear_wgrad(dy, x):
+	"""dw[N, K] = dy.T @ x in float32."""
+	M, N = dy.shape
+	K = x.shape[1]
+	assert x.shape[0] == M and dy.stride(1) == 1 and x.stride(1) == 1
+	dw = torch.empty((N, K), dtype=torch.float32, device=dy.device)
+	gemm(dy, x, dw, N, K, M, dy.stride(0), x.stride(0), K, a_layout=L.MN_MAJOR, b_layout=L.MN_MAJOR)
+	return dw
+
+
+def colsum(x):
+	"""sum over rows -> float32 [N] (bias gradient)."""
+	M, N = x.shape
+	assert x.stride(1) == 1
+	out = torch.empty(N, dtype=torch.float32, device=x.device)
+	L.check(L.load().vitk_colsum(L.ptr(x), L.ptr(out), M, N, x.stride(0), 0, L.dtype_code(x.dtype), L.stream()))
+	return out
+
+
+def norm_fwd(x, weight, bias, kind, eps, unit_offset=True, res=None):
+	"""kind 'layernorm' | 'rmsnorm'.  x: [rows, d] contiguous.  With res: s = x + res is normalised and returned.
+	Returns (y, s_or_None, mean_or_None, rstd)."""
+	rows, d = x.shape
+	assert x.is_contiguous() and (res is None or res.is_contiguous())
+	y = torch.empty_like(x)
+	s = torch.empty_like(x) if res is not None else None
+	rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+	lib = L.load()
+	dt = L.dtype_code(x.dtype)
+	if kind == "layernorm":
+		mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+		L.check(lib.vitk_layernorm_fwd(L.ptr(x), L.ptr(res), L.ptr(weight), L.ptr(bias), L.ptr(y), L.ptr(s), L.ptr(mean), L.ptr(rstd), rows, d, eps, dt, L.stream()))
+		return y, s, mean, rstd
+	L.check(lib.vitk_rmsnorm_fwd(L.ptr(x), L.ptr(res), L.ptr(weight), L.ptr(y), L.ptr(s), L.ptr(rstd), rows, d, eps, int(unit_offset), dt, L.stream()))
+	return y, s, None, rstd
+
+
+def norm_bwd(dy, x, weight, mean, rstd, kind, unit_offset=True, dres=None):
+	"""Returns (dx, dweight_f32, dbias_f32_or_None); dres (same shape as x) is added into dx."""
+	rows, d = x.shape
+	assert dy.is_contiguous() and x.is_contiguous() and (dres is None or dres.is_contiguous())
+	dx = torch.empty_like(x)
+	dw = torch.zeros(d, dtype=torch.float32, device=x.device)
+	lib = L.load()
+	dt = L.dtype_code(x.dtype)
+	if kind == "layernorm":
+		db = torch.zeros(d, dtype=torch.float32, device=x.device)
+		L.check(lib.vitk_layernorm_bwd(L.ptr(dy), L.ptr(x), L.ptr(weight), L.ptr(mean), L.ptr(rstd), L.ptr(dres), L.ptr(dx), L.ptr(dw), L.ptr(db), rows, d, dt, L.stream()))
+		return dx, dw, db
+	L.check(lib.vitk_rmsnorm_bwd(L.ptr(dy), L.ptr(x), L.ptr(weight), L.ptr(rstd), L.ptr(dres), L.ptr(dx), L.ptr(dw), rows, d, int(unit_offset), dt, L.stream()))
+	return dx, dw, None
+
+
+def attention_fwd(q, k, v, B, n_head, Sq, Skv, dh, scale=0.0):
+	"""q: [B*Sq, >=h*dh] view, k/v: [B*Skv, ...] views (unit inner stride).  Returns (out [B*Sq, h*dh], lse [B,h,Sq])."""
+	out = torch.empty((B * Sq, n_head * dh), dtype=q.dtype, device=q.device)
+	lse = torch.empty((B, n_head, Sq), dtype=torch.float32, device=q.device)
+	assert q.stride(1) == 1 and k.stride(1) == 1 and v.stride(1) == 1
+	L.check(L.load().vitk_attention_fwd(L.ptr(q), L.ptr(k), L.ptr(v), L.ptr(out), L.ptr(lse), B, n_head, Sq, Skv, dh,
+		q.stride(0), k.stride(0), v.stride(0), out.stride(0), scale, L.dtype_code(q.dtype), L.stream()))
+	return out, lse
+
+
+def attention_bwd(dout, q, k, v, out, lse, dq, dk, dv, B, n_head, Sq, Skv, dh, scale=0.0):
+	"""Writes dq/dk/dv (views with unit inner stride, e.g. column slices of one [rows, 3d] buffer)."""
+	assert dout.stride(1) == 1 and dout.stride(0) == out.stride(0)
+	L.check(L.load().vitk_attention_bwd(L.ptr(dout), L.ptr(q), L.ptr(k), L.ptr(v), L.ptr(out), L.ptr(lse), L.ptr(dq), L.ptr(dk), L.ptr(dv),
+		B, n_head, Sq, Skv, dh, q.stride(0), k.stride(0), v.stride(0), out.stride(0), dq.stride(0), dk.stride(0), dv.stride(0),
+		scale, L.dtype_code(q.dtype), L.stream()))
+
+
+def gated_act_fwd(u, F, act):
+	M = u.shape[0]
+	a = torch.empty((M, F), dtype=u.dtype, device=u.device)
+	L.check(L.load().vitk_gated_act_fwd(L.ptr(u), L.ptr(a), M, F, u.stride(0), act, L.dtype_code(u.dtype), L.stream()))
+	return a
+
+
+def gated_act_bwd(da, u, F, act):
+	M = u.shape[0]
+	du = torch.empty_like(u)
+	L.check(L.load().vitk_gated_act_bwd(L.ptr(da), L.ptr(u), L.ptr(du), M, F, u.stride(0), act, L.dtype_code(u.dtype), L.stream()))
+	return du
+
+
+def scale_residual(x, res, gamma):
+	y = torch.empty_like(x)
+	rows, d = x.shape
+	L.check(L.load().vitk_scale_residual(L.ptr(x), L.ptr(res), L.ptr(gamma), L.ptr(y), rows, d, L.dtype_code(x.dtype), L.stream()))
+	return y
+
+
+def layerscale_bwd(dy, branch, gamma):
+	rows, d = dy.shape
+	dbranch = torch.empty_like(dy)
+	dgamma = torch.zeros(d, dtype=torch.float32, device=dy.device)
+	L.check(L.load().vitk_layerscale_bwd(L.ptr(dy), L.ptr(branch), L.ptr(gamma), L.ptr(dbranch), L.ptr(dgamma), rows, d, L.dtype_code(dy.dtype), L.stream()))
+	return dbranch, dgamma
+
+
+# --------------------------------------------------------------------------------------------------
+# autograd Functions
+# --------------------------------------------------------------------------------------------------
+
+def _flat(x):
+	x2 = x.reshape(-1, x.shape[-1])
+	return x2 if x2.is_contiguous() else x2.contiguous()
+
+
+class LinearFn(torch.autograd.Function):
+	"""y = act(x @ w.T + b) — nn.Linear (+ elementwise activation) on the MFMA GEMM."""
+
+	@staticmethod
+	def forward(ctx, x, w, b, act):
+		L.require_gpu(x, w)
+		dt = compute_dtype(x)
+		x2 = _flat(cast(x, dt))
+		wc = weight_as(w, dt)
+		bc = f32(b)
+		if act != L.ACT_NONE:
+			y, pre = linear_fwd(x2, wc, bc, act=act, save_pre=True)
+		else:
+			y, pre = linear_fwd(x2, wc, bc), None
+		ctx.save_for_backward(x2, w, pre)
+		ctx.meta = (x.shape, x.dtype, b, act, dt)
+		return y.reshape(*x.shape[:-1], w.shape[0])
+
+	@staticmethod
+	def backward(ctx, dy):
+		x2, w, pre = ctx.saved_tensors
+		xshape, xdtype, b, act, dt = ctx.meta
+		dy2 = _flat(cast(dy, dt))
+		if pre is not None:
+			du = torch.empty_like(dy2)
+			L.check(L.load().vitk_act_bwd(L.ptr(dy2), L.ptr(pre), L.ptr(du), dy2.numel(), act, L.dtype_code(dt), L.stream()))
+			dy2 = du
+		wc = weight_as(w, dt)
+		dx = linear_dgrad(dy2, wc).reshape(xshape) if ctx.needs_input_grad[0] else None
+		dw = grad_as(linear_wgrad(dy2, x2), w) if ctx.needs_input_grad[1] else None
+		db = grad_as(colsum(dy2), b) if (b is not None and ctx.needs_input_grad[2]) else None
+		if dx is not None and dx.dtype != xdtype:
+			dx = cast(dx, xdtype)
+		return dx, dw, db, None
+
+
+class NormFn(torch.autograd.Function):
+	"""LayerNorm / RMSNorm over the last dimension."""
+
+	@staticmethod
+	def forward(ctx, x, weight, bias, kind, eps, unit_offset):
+		L.require_gpu(x, weight)
+		dt = compute_dtype(x) if kind == "layernorm" else (x.dtype if x.dtype in (torch.float32, torch.bfloat16) else torch.float32)
+		x2 = _flat(cast(x, dt))
+		wf, bf = f32(weight), f32(bias)
+		y, _, mean, rstd = norm_fwd(x2, wf, bf, kind, eps, unit_offset)
+		ctx.save_for_backward(x2, weight, mean, rstd)
+		ctx.meta = (x.shape, x.dtype, bias, kind, unit_offset)
+		return y.reshape(x.shape)
+
+	@staticmethod
+	def backward(ctx, dy):
+		x2, weight, mean, rstd = ctx.saved_tensors
+		xshape, xdtype, bias, kind, unit_offset = ctx.meta
+		dy2 = _flat(cast(dy, x2.dtype))
+		dx, dw, db = norm_bwd(dy2, x2, f32(weight), mean, rstd, kind, unit_offset)
+		dx = dx.reshape(xshape)
+		if dx.dtype != xdtype:
+			dx = cast(dx, xdtype)
+		return dx, grad_as(dw, weight), grad_as(db, bias) if bias is not None else None, None, None, None
+
+
+def _ffn_forward(x2, w1, b1, w2, b2, act, gated, residual=None, gamma=None):
+	"""fc_in -> act / gate*act -> fc_out (layers/transformers.py:45-57).  Returns (y, u, a)."""
+	if gated:
+		u = linear_fwd(x2, w1, b1)
+		F = w2.shape[1]
+		a = gated_act_fwd(u, F, act)
+	else:
+		a, u = linear_fwd(x2, w1, b1, act=act, save_pre=True)
+	y = linear_fwd(a, w2, b2, residual=residual, gamma=gamma)
+	return y, u, a
+
+
+def _ffn_backward(dy2, x2, u, a, w1, w2, act, gated, need_dx=True):
+	"""Returns (dx, dw1, db1, dw2, db2) with float32 parameter gradients."""
+	dw2 = linear_wgrad(dy2, a)
+	db2 = colsum(dy2)
+	if gated:
+		da = linear_dgrad(dy2, w2)
+		du = gated_act_bwd(da, u, w2.shape[1], act)
+	else:
+		du = linear_dgrad(dy2, w2, act=act, pre=u)
+	dw1 = linear_wgrad(du, x2)
+	db1 = colsum(du)
+	dx = linear_dgrad(du, w1) if need_dx else None
+	return dx, dw1, db1, dw2, db2
+
+
+class FeedForwardFn(torch.autograd.Function):
+	@staticmethod
+	def forward(ctx, x, w1, b1, w2, b2, act, gated):
+		L.require_gpu(x, w1)
+		dt = compute_dtype(x)
+		x2 = _flat(cast(x, dt))
+		y, u, a = _ffn_forward(x2, weight_as(w1, dt), f32(b1), weight_as(w2, dt), f32(b2), act, gated)
+		ctx.save_for_backward(x2, u, a, w1, w2)
+		ctx.meta = (x.shape, x.dtype, b1, b2, act, gated, dt)
+		return y.reshape(x.shape[:-1] + (w2.shape[0],))
+
+	@staticmethod
+	def backward(ctx, dy):
+		x2, u, a, w1, w2 = ctx.saved_tensors
+		xshape, xdtype, b1, b2, act, gated, dt = ctx.meta
+		dy2 = _flat(cast(dy, dt))
+		dx, dw1, db1, dw2, db2 = _ffn_backward(dy2, x2, u, a, weight_as(w1, dt), weight_as(w2, dt), act, gated, ctx.needs_input_grad[0])
+		if dx is not None:
+			dx = dx.reshape(xshape)
+			if dx.dtype != xdtype:
+				dx = cast(dx, xdtype)
+		return dx, grad_as(dw1, w1), grad_as(db1, b1), grad_as(dw2, w2), grad_as(db2, b2), None, None
+
+
+def _mha_forward(x2, wqkv, wo, bo, B, S, n_head, residual=None, gamma=None):
+	"""qkv projection -> attention -> out projection (layers/attention.py:27-48).  Returns (y, qkv, o, lse)."""
+	d = x2.shape[1]
+	dh = d // n_head
+	qkv = linear_fwd(x2, wqkv)
+	o, lse = attention_fwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], B, n_head, S, S, dh)
+	y = linear_fwd(o, wo, bo, residual=residual, gamma=gamma)
+	return y, qkv, o, lse
+
+
+def _mha_backward(dy2, x2, qkv, o, lse, wqkv, wo, B, S, n_head, need_dx=True):
+	"""Returns (dx, dwqkv, dwo, dbo)."""
+	d = x2.shape[1]
+	dh = d // n_head
+	dwo = linear_wgrad(dy2, o)
+	dbo = colsum(dy2)
+	do = linear_dgrad(dy2, wo)
+	dqkv = torch.empty_like(qkv)
+	attention_bwd(do, qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], o, lse, dqkv[:, :d], dqkv[:, d:2 * d], dqkv[:, 2 * d:], B, n_head, S, S, dh)
+	dwqkv = linear_wgrad(dqkv, x2)
+	dx = linear_dgrad(dqkv, wqkv) if need_dx else None
+	return dx, dwqkv, dwo, dbo
+
+
+class MHAFn(torch.autograd.Function):
+	@staticmethod
+	def forward(ctx, x, wqkv, wo, bo, n_head):
+		L.require_gpu(x, wqkv)
+		dt = compute_dtype(x)
+		B, S, d = x.shape
+		x2 = _flat(cast(x, dt))
+		y, qkv, o, lse = _mha_forward(x2, weight_as(wqkv, dt), weight_as(wo, dt), f32(bo), B, S, n_head)
+		ctx.save_for_backward(x2, qkv, o, lse, wqkv, wo)
+		ctx.meta = (x.shape, x.dtype, bo, n_head, dt)
+		return y.reshape(B, S, d)
+
+	@staticmethod
+	def backward(ctx, dy):
+		x2, qkv, o, lse, wqkv, wo = ctx.saved_tensors
+		(B, S, d), xdtype, bo, n_head, dt = ctx.meta
+		dy2 = _flat(cast(dy, dt))
+		dx, dwqkv, dwo, dbo = _mha_backward(dy2, x2, qkv, o, lse, weight_as(wqkv, dt), weight_as(wo, dt), B, S, n_head, ctx.needs_input_grad[0])
+		if dx is not None:
+			dx = dx.reshape(B, S, d)
+			if dx.dtype != xdtype:
+				dx = cast(dx, xdtype)
+		return dx, grad_as(dwqkv, wqkv), grad_as(dwo, wo), grad_as(dbo, bo), None
+
+
+class ViTBlockFn(torch.autograd.Function):
+	"""One pre-norm transformer block (layers/vit.py:27-57, MHA attention) as a single autograd node:
+	norm -> qkv GEMM -> attention -> out-proj GEMM (+bias, +residual in the epilogue) -> norm ->
+	fc_in GEMM (+bias, +activation in the epilogue) -> fc_out GEMM (+bias, +residual in the epilogue).
+	With LayerScale the residual add runs as a separate kernel because the branch output is needed
+	for the LayerScale gradient."""
+
+	@staticmethod
+	def forward(ctx, x, n1w, n1b, wqkv, wo, bo, ls1, n2w, n2b, w1, b1, w2, b2, ls2, cfg):
+		L.require_gpu(x, wqkv)
+		kind, eps, unit_offset, n_head, act, gated = cfg
+		dt = compute_dtype(x)
+		B, S, d = x.shape
+		x0 = _flat(cast(x, dt))
+		wqkv_c, wo_c, w1_c, w2_c = (weight_as(t, dt) for t in (wqkv, wo, w1, w2))
+		n1, _, mean1, rstd1 = norm_fwd(x0, f32(n1w), f32(n1b), kind, eps, unit_offset)
+		if ls1 is None:
+			x1, qkv, o, lse = _mha_forward(n1, wqkv_c, wo_c, f32(bo), B, S, n_head, residual=x0)
+			br1 = None
+		else:
+			br1, qkv, o, lse = _mha_forward(n1, wqkv_c, wo_c, f32(bo), B, S, n_head)
+			x1 = scale_residual(br1, x0, f32(ls1))
+		n2, _, mean2, rstd2 = norm_fwd(x1, f32(n2w), f32(n2b), kind, eps, unit_offset)
+		if ls2 is None:
+			x2, u, a = _ffn_forward(n2, w1_c, f32(b1), w2_c, f32(b2), act, gated, residual=x1)
+			br2 = None
+		else:
+			br2, u, a = _ffn_forward(n2, w1_c, f32(b1), w2_c, f32(b2), act, gated)
+			x2 = scale_residual(br2, x1, f32(ls2))
+		ctx.save_for_backward(x0, n1, mean1, rstd1, qkv, o, lse, br1, x1, n2, mean2, rstd2, u, a, br2,
+			n1w, wqkv, wo, ls1, n2w, w1, w2, ls2)
+		ctx.meta = (x.shape, x.dtype, n1b, bo, n2b, b1, b2, cfg, dt)
+		return x2.reshape(B, S, d)
+
+	@staticmethod
+	def backward(ctx, dy):
+		(x0, n1, mean1, rstd1, qkv, o, lse, br1, x1, n2, mean2, rstd2, u, a, br2, n1w, wqkv, wo, ls1, n2w, w1, w2, ls2) = ctx.saved_tensors
+		(B, S, d), xdtype, n1b, bo, n2b, b1, b2, cfg, dt = ctx.meta
+		kind, eps, unit_offset, n_head, act, gated = cfg
+		wqkv_c, wo_c, w1_c, w2_c = (weight_as(t, dt) for t in (wqkv, wo, w1, w2))
+		dx2 = _flat(cast(dy, dt))
+		# feed-forward branch
+		if ls2 is not None:
+			dbr2, dls2 = layerscale_bwd(dx2, br2, f32(ls2))
+		else:
+			dbr2, dls2 = dx2, None
+		dn2, dw1, db1, dw2, db2 = _ffn_backward(dbr2, n2, u, a, w1_c, w2_c, act, gated)
+		dx1, dn2w, dn2b = norm_bwd(dn2, x1, f32(n2w), mean2, rstd2, kind, unit_offset, dres=dx2)
+		# attention branch
+		if ls1 is not None:
+			dbr1, dls1 = layerscale_bwd(dx1, br1, f32(ls1))
+		else:
+			dbr1, dls1 = dx1, None
+		dn1, dwqkv, dwo, dbo = _mha_backward(dbr1, n1, qkv, o, lse, wqkv_c, wo_c, B, S, n_head)
+		dx0, dn1w, dn1b = norm_bwd(dn1, x0, f32(n1w), mean1, rstd1, kind, unit_offset, dres=dx1)
+		dx0 = dx0.reshape(B, S, d)
+		if dx0.dtype != xdtype:
+			dx0 = cast(dx0, xdtype)
+		return (dx0, grad_as(dn1w, n1w), grad_as(dn1b, n1b), grad_as(dwqkv, wqkv), grad_as(dwo, wo), grad_as(dbo, bo), grad_as(dls1, ls1),
+			grad_as(dn2w, n2w), grad_as(dn2b, n2b), grad_as(dw1, w1), grad_as(db1, b1), grad_as(dw2, w2), grad_as(db2, b2), grad_as(dls2, ls2), None)
+
+
+class PatchEmbedFn(torch.autograd.Function):
+	"""images -> tokens [B, P*P + 1, d]: im2col-free patch GEMM + bias + pos_embed in the epilogue, class-token row
+	written by a small kernel (models/vit.py:46-52)."""
+
+	@staticmethod
+	def forward(ctx, images, w, b, class_token, pos_embed, n_patch):
+		L.require_gpu(images, w)
+		dt = compute_dtype(images)
+		Bn, C, H, W = images.shape
+		assert H == W, "Patchify method is implemented for square images only"
+		img = cast(images, dt)
+		P2 = n_patch * n_patch
+		d = w.shape[0]
+		K = w.shape[1]
+		x = torch.empty((Bn, P2 + 1, d), dtype=dt, device=images.device)
+		pos = f32(pos_embed).reshape(P2 + 1, d)
+		gemm(img, weight_as(w, dt), x, Bn * P2, d, K, K, K, d, bias=f32(b), patch=(n_patch, C, H), tokens_per_image=P2, pos=pos)
+		L.check(L.load().vitk_cls_rows(L.ptr(x), L.ptr(f32(class_token)), L.ptr(pos), Bn, P2 + 1, d, L.dtype_code(dt), L.stream()))
+		ctx.save_for_backward(img, w)
+		ctx.meta = (images.shape, images.dtype, b, class_token, pos_embed, n_patch, dt)
+		return x
+
+	@staticmethod
+	def backward(ctx, dx):
+		img, w = ctx.saved_tensors
+		(Bn, C, H, W), idtype, b, class_token, pos_embed, n_patch, dt = ctx.meta
+		lib = L.load()
+		P2 = n_patch * n_patch
+		d, K = w.shape
+		dx = cast(dx, dt)
+		dtc = L.dtype_code(dt)
+		dpos = torch.empty((P2 + 1, d), dtype=torch.float32, device=dx.device)
+		L.check(lib.vitk_batch_sum(L.ptr(dx), L.ptr(dpos), Bn, P2 + 1, d, 0, dtc, L.stream()))
+		dtok = torch.empty((Bn * P2, d), dtype=dt, device=dx.device)
+		L.check(lib.vitk_drop_cls_rows(L.ptr(dx), L.ptr(dtok), Bn, P2 + 1, d, dtc, L.stream()))
+		patches = torch.empty((Bn * P2, K), dtype=dt, device=dx.device)
+		L.check(lib.vitk_patchify(L.ptr(img), L.ptr(patches), Bn, C, H, n_patch, dtc, L.stream()))
+		dw = linear_wgrad(dtok, patches)
+		db = colsum(dtok)
+		dimg = None
+		if ctx.needs_input_grad[0]:
+			dpatch = linear_dgrad(dtok, weight_as(w, dt))
+			dimg = torch.empty((Bn, C, H, W), dtype=dt, device=dx.device)
+			L.check(lib.vitk_unpatchify(L.ptr(dpatch), L.ptr(dimg), Bn, C, H, n_patch, dtc, L.stream()))
+			if dimg.dtype != idtype:
+				dimg = cast(dimg, idtype)
+		dcls = dpos[0:1].clone()
+		return dimg, grad_as(dw, w), grad_as(db, b), grad_as(dcls.reshape(class_token.shape), class_token), grad_as(dpos.reshape(pos_embed.shape), pos_embed), None
+
+
+class ClsHeadFn(torch.autograd.Function):
+	"""logits = x[:, 0] @ w.T + b (models/vit.py:63-65): the class-token row is read in place through the row stride."""
+
+	@staticmethod
+	def forward(ctx, x, w, b):
+		L.require_gpu(x, w)
+		dt = compute_dtype(x)
+		xc = cast(x, dt)
+		Bn, S, d = xc.shape
+		rows0 = xc.reshape(Bn * S, d)[::S]  # [B, d] view with row stride S*d
+		y = linear_fwd(rows0, weight_as(w, dt), f32(b))
+		ctx.save_for_backward(xc, w)
+		ctx.meta = (x.dtype, b, dt)
+		return y
+
+	@staticmethod
+	def backward(ctx, dy):
+		xc, w = ctx.saved_tensors
+		xdtype, b, dt = ctx.meta
+		Bn, S, d = xc.shape
+		dy2 = cast(dy, dt)
+		rows0 = xc.reshape(Bn * S, d)[::S]
+		dw = linear_wgrad(dy2, rows0)
+		db = colsum(dy2)
+		dx = None
+		if ctx.needs_input_grad[0]:
+			dx = torch.zeros((Bn, S, d), dtype=dt, device=dy.device)
+			linear_dgrad(dy2, weight_as(w, dt), out=dx.reshape(Bn * S, d)[::S])
+			if dx.dtype != xdtype:
+				dx = cast(dx, xdtype)
+		return dx, grad_as(dw, w), grad_as(db, b)
+
+
+class CeKdLossFn(torch.autograd.Function):
+	"""(1-alpha) * CE(logits, y; label_smoothing) + alpha * tau^2 * KL(softmax(t/tau) || softmax(s/tau)), batchmean
+	(main.py:106-109, deit_trainer.py:30-45).  teacher=None gives plain cross entropy."""
+
+	@staticmethod
+	def forward(ctx, logits, labels, teacher, label_smoothing, alpha, tau):
+		L.require_gpu(logits, labels)
+		lg = logits.contiguous()
+		if lg.dtype not in (torch.float32, torch.bfloat16):
+			raise TypeError(lg.dtype)
+		t = None if teacher is None else cast(teacher.detach(), lg.dtype)
+		Bn, C = lg.shape
+		loss = torch.zeros(1, dtype=torch.float32, device=lg.device)
+		dlogits = torch.empty_like(lg)
+		L.check(L.load().vitk_ce_kd_loss(L.ptr(lg), L.ptr(labels.contiguous()), L.ptr(t), L.ptr(loss), L.ptr(dlogits), Bn, C,
+			float(label_smoothing), float(alpha), float(tau), L.dtype_code(lg.dtype), L.stream()))
+		ctx.save_for_backward(dlogits)
+		return loss[0]
+
+	@staticmethod
+	def backward(ctx, g):
+		(dlogits,) = ctx.saved_tensors
+		return dlogits * g.to(dlogits.dtype), None, None, None, None, None
+
+
+def cross_entropy(logits, labels, label_smoothing=0.0):
+	return CeKdLossFn.apply(logits, labels, None, label_smoothing, 0.0, 1.0)
+
+
+def deit_loss(student, labels, teacher, alpha=0.5, tau=1.0, label_smoothing=0.0):
+	return CeKdLossFn.apply(student, labels, teacher, label_smoothing, alpha, tau)
+
+
+class GatedActFn(torch.autograd.Function):
+	"""a = gate * act(up) for u = [gate | up] (layers/transformers.py:48-50)."""
+
+	@staticmethod
+	def forward(ctx, u, act):
+		u2 = _flat(u)
+		F = u2.shape[1] // 2
+		ctx.save_for_backward(u2)
+		ctx.meta = (u.shape, act, F)
+		return gated_act_fwd(u2, F, act).reshape(u.shape[:-1] + (F,))
+
+	@staticmethod
+	def backward(ctx, da):
+		(u2,) = ctx.saved_tensors
+		ushape, act, F = ctx.meta
+		return gated_act_bwd(_flat(cast(da, u2.dtype)), u2, F, act).reshape(ushape), None
+
+
+class ScaleResidualFn(torch.autograd.Function):
+	"""x + gamma * branch (layers/vit.py:44-47,52-55); gamma None = plain residual add."""
+
+	@staticmethod
+	def forward(ctx, branch, x, gamma):
+		L.require_gpu(branch, x)
+		dt = compute_dtype(x) if x.dtype != branch.dtype else x.dtype
+		b2, x2 = _flat(cast(branch, dt)), _flat(cast(x, dt))
+		ctx.save_for_backward(b2 if gamma is not None else None, gamma)
+		ctx.meta = (x.shape, x.dtype, branch.dtype, dt)
+		return scale_residual(b2, x2, f32(gamma)).reshape(x.shape)
+
+	@staticmethod
+	def backward(ctx, dy):
+		b2, gamma = ctx.saved_tensors
+		xshape, xdtype, bdtype, dt = ctx.meta
+		dy2 = _flat(cast(dy, dt))
+		if gamma is None:
+			dbranch, dgamma = dy2, None
+		else:
+			dbranch, dgamma = layerscale_bwd(dy2, b2, f32(gamma))
+		dbranch = dbranch.reshape(xshape)
+		dx = dy2.reshape(xshape)
+		return (dbranch if dbranch.dtype == bdtype else cast(dbranch, bdtype)), (dx if dx.dtype == xdtype else cast(dx, xdtype)), grad_as(dgamma, gamma)
+
+
+class PatchifyFn(torch.autograd.Function):
+	"""Non-overlapping patch gather 'b c (p1 hp) (p2 wp) -> b (p1 p2) (c hp wp)' (layers/embeddings.py:7-16)."""
+
+	@staticmethod
+	def forward(ctx, images, n_patch):
+		L.require_gpu(images)
+		Bn, C, H, W = images.shape
+		img = images.contiguous()
+		p = H // n_patch
+		out = torch.empty((Bn, n_patch * n_patch, C * p * p), dtype=img.dtype, device=img.device)
+		L.check(L.load().vitk_patchify(L.ptr(img), L.ptr(out), Bn, C, H, n_patch, L.dtype_code(img.dtype), L.stream()))
+		ctx.meta = (images.shape, n_patch)
+		return out
+
+	@staticmethod
+	def backward(ctx, dp):
+		(Bn, C, H, W), n_patch = ctx.meta
+		dp = dp.contiguous()
+		dimg = torch.empty((Bn, C, H, W), dtype=dp.dtype, device=dp.device)
+		L.check(L.load().vitk_unpatchify(L.ptr(dp), L.ptr(dimg), Bn, C, H, n_patch, L.dtype_code(dp.dtype), L.stream()))
+		return dimg, None
+
+
+_dropout_calls = [0]
+
+
+class DropoutFn(torch.autograd.Function):
+	@staticmethod
+	def forward(ctx, x, p, seed):
+		L.require_gpu(x)
+		xc = x.contiguous()
+		y = torch.empty_like(xc)
+		L.check(L.load().vitk_dropout(L.ptr(xc), L.ptr(y), xc.numel(), p, seed, L.dtype_code(xc.dtype), L.stream()))
+		ctx.meta = (p, seed)
+		return y
+
+	@staticmethod
+	def backward(ctx, dy):
+		p, seed = ctx.meta
+		dyc = dy.contiguous()
+		dx = torch.empty_like(dyc)
+		L.check(L.load().vitk_dropout(L.ptr(dyc), L.ptr(dx), dyc.numel(), p, seed, L.dtype_code(dyc.dtype), L.stream()))
+		return dx, None, None
+
+
+def dropout(x, p):
+	"""Training-mode inverted dropout.  The seed comes from torch's CPU generator (so torch.manual_seed makes runs
+	repeatable) plus a per-call counter; no device synchronisation."""
+	_dropout_calls[0] += 1
+	seed = (torch.initial_seed() * 0x9E3779B1 + _dropout_calls[0] * 0x85EBCA77) & 0xFFFFFFFFFFFFFFFF
+	return DropoutFn.apply(x, float(p), seed)
