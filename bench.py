@@ -1,0 +1,183 @@
+"""Headline benchmark: train images/sec of ViT-B/16 at 224x224, bf16 compute, on N MI355X of one node.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--config vit_b16|vit_tiny]
+
+For N > 1 it is launched as `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`
+(one rank per GPU, RCCL).  A step = forward + cross-entropy + backward + gradient all-reduce (N > 1) +
+fused AdamW on synthetic data already resident in HBM.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CONFIGS = {
+	# BASELINE config 4: 86,538,472 parameters, 105.38 GFLOP per image per training step (3 x forward, 2 x MAC)
+	"vit_b16": dict(d_model=768, n_head=12, n_block=12, n_patch=14, d_ff=3072, out_d=1000, chw=(3, 224, 224), batch=256),
+	# BASELINE config 1 geometry (ViT-Tiny patch 4 on 32x32)
+	"vit_tiny": dict(d_model=192, n_head=3, n_block=12, n_patch=8, d_ff=768, out_d=10, chw=(3, 32, 32), batch=512),
+}
+PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak of one MI355X
+
+
+def train_flops_per_image(c):
+	d, f, L_ = c["d_model"], c["d_ff"], c["n_block"]
+	n = c["n_patch"] ** 2 + 1
+	p = c["chw"][1] // c["n_patch"]
+	block = 2 * n * d * 3 * d + 4 * n * n * d + 2 * n * d * d + 4 * n * d * f
+	fwd = L_ * block + 2 * (n - 1) * (c["chw"][0] * p * p) * d + 2 * d * c["out_d"]
+	return 3.0 * fwd
+
+
+def make_config(c):
+	from vit_amd.layers import MHA
+
+	class Cfg:
+		attention = MHA
+		norm = nn.LayerNorm
+		activation = "gelu"
+		use_layer_scale = False
+		use_qk_norm = False
+		dropout = 0.0
+	for k in ("d_model", "n_head", "n_block", "n_patch", "d_ff", "out_d", "chw"):
+		setattr(Cfg, k, c[k])
+	return Cfg()
+
+
+def cpu_baseline(c, seconds=20.0):
+	"""The CPU oracle (explicit-formula restatement of the reference modules, float32, torch autograd for the
+	backward) timed on this host: forward + cross entropy + backward at a small batch, bounded to ~`seconds`."""
+	from oracle import vit_oracle as O
+	from vit_amd.models import ViT
+	torch.manual_seed(0)
+	model = ViT(make_config(c))
+	sd = {k: v.detach() for k, v in model.state_dict().items()}
+	batch = 8 if c["d_model"] >= 768 else 128
+	x = torch.randn(batch, *c["chw"])
+	y = torch.randint(0, c["out_d"], (batch,))
+	fwd = lambda im, s: O.vit_fwd(im, s, c["n_patch"], c["n_block"], c["n_head"], "layernorm", "gelu")
+	cores = torch.get_num_threads()
+	times = []
+	t_begin = time.time()
+	O.loss_and_grads(fwd, sd, x, y)  # warm-up
+	while len(times) < 5 and (time.time() - t_begin) < seconds:
+		t0 = time.time()
+		O.loss_and_grads(fwd, sd, x, y)
+		times.append(time.time() - t0)
+	med = sorted(times)[len(times) // 2]
+	return {"value": round(batch / med, 2), "unit": "images/sec", "cores": cores, "kind": "port",
+		"sample": f"{len(times)} timed fwd+loss+bwd iterations of the float32 CPU oracle at batch {batch} (same model config), median"}
+
+
+def main():
+	ap = argparse.ArgumentParser()
+	ap.add_argument("--gpus", type=int, default=1)
+	ap.add_argument("--steps", type=int, default=10)
+	ap.add_argument("--warmup", type=int, default=3)
+	ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the config's)")
+	ap.add_argument("--config", default="vit_b16", choices=sorted(CONFIGS))
+	ap.add_argument("--no-cpu-baseline", action="store_true")
+	ap.add_argument("--no-kernel-timing", action="store_true")
+	args = ap.parse_args()
+
+	world = int(os.environ.get("WORLD_SIZE", "1"))
+	rank = int(os.environ.get("RANK", "0"))
+	local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+	if world != args.gpus:
+		raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus}")
+	torch.cuda.set_device(local_rank)
+	dev = torch.device("cuda", local_rank)
+	if world > 1:
+		os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+		dist.init_process_group("nccl", device_id=dev)
+
+	from vit_amd import dp, ops
+	from vit_amd.models import ViT
+
+	c = CONFIGS[args.config]
+	batch = args.batch or c["batch"]
+	torch.manual_seed(0)
+	model = ViT(make_config(c)).to(dev)
+	trainer = dp.Trainer(model, lr=1e-3, weight_decay=0.05)
+	g = torch.Generator(device="cpu").manual_seed(1234 + rank)
+	x = torch.randn(batch, *c["chw"], generator=g).to(dev)
+	y = torch.randint(0, c["out_d"], (batch,), generator=g).to(dev)
+
+	def step():
+		trainer.zero_grad()
+		with torch.autocast("cuda", dtype=torch.bfloat16):
+			logits = model(x)
+			loss = ops.cross_entropy(logits, y)
+		loss.backward()
+		trainer.step()
+		return loss
+
+	def barrier():
+		if world > 1:
+			dist.barrier()
+		torch.cuda.synchronize()
+
+	for _ in range(args.warmup):
+		step()
+	if not args.no_kernel_timing and rank == 0:
+		ops.GEMM_PROFILE = []
+	barrier()
+	t0 = time.perf_counter()
+	for _ in range(args.steps):
+		loss = step()
+	barrier()
+	elapsed = time.perf_counter() - t0
+	t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+	if world > 1:
+		dist.all_reduce(t, op=dist.ReduceOp.MAX)
+	elapsed = t.item()
+	final_loss = loss.item()
+	assert final_loss == final_loss, "loss is NaN"
+
+	if rank == 0:
+		value = batch * world * args.steps / elapsed
+		flops_img = train_flops_per_image(c)
+		out = {
+			"metric": "train images/sec (node) ViT-B/16 224x224 bf16" if args.config == "vit_b16" else "train images/sec (node) ViT-Tiny/4 32x32 bf16",
+			"value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+			"ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+			"dtype": "bf16", "data": "synthetic",
+			"config": {"workload": f"{args.config}: ViT d{c['d_model']}/h{c['n_head']}/L{c['n_block']}/ff{c['d_ff']} patch{c['chw'][1] // c['n_patch']} at {c['chw'][1]}x{c['chw'][2]}, "
+				f"{c['n_patch'] ** 2 + 1} tokens, fwd+CE+bwd+AdamW, fp32 master weights, bf16 activations", "global_batch": batch * world, "per_gpu_batch": batch,
+				"parallelism": f"dp{world}"},
+			"train_gflop_per_image": round(flops_img / 1e9, 3),
+			"mfma_util_pct": round(100.0 * value * flops_img / (world * PEAK_BF16_TFLOPS * 1e12), 2),
+			"final_loss": round(final_loss, 4),
+		}
+		if ops.GEMM_PROFILE:
+			prof, ops.GEMM_PROFILE = ops.GEMM_PROFILE, None
+			agg = {}
+			for label, flops, e0, e1 in prof:
+				a = agg.setdefault(label, [0.0, 0.0, 0])
+				a[0] += flops
+				a[1] += e0.elapsed_time(e1) * 1e-3
+				a[2] += 1
+			dom = max(agg.items(), key=lambda kv: kv[1][1])
+			label, (fl, sec, n) = dom
+			achieved = fl / sec / 1e12
+			out["roofline"] = {"bound": "mfma", "kernel": label, "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+				"frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None, "launches": n, "avg_launch_ms": round(1e3 * sec / n, 4),
+				"gflop_per_launch": round(fl / n / 1e9, 2),
+				"all_gemm_kernels": {k: {"tflops": round(v[0] / v[1] / 1e12, 1), "ms_per_step": round(1e3 * v[1] / args.steps, 3), "launches_per_step": v[2] // args.steps} for k, v in agg.items()}}
+		if not args.no_cpu_baseline and world == 1:
+			out["cpu_baseline"] = cpu_baseline(c)
+		print(json.dumps(out), flush=True)
+	if world > 1:
+		dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+	main()

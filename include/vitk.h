@@ -105,6 +105,8 @@ typedef struct vitk_gemm_desc {
 } vitk_gemm_desc;
 
 int vitk_gemm(const vitk_gemm_desc* desc, void* stream);
+/* 1 if vitk_gemm would run this problem on the bf16 MFMA kernel, 0 if on the generic float32-MFMA kernel. */
+int vitk_gemm_uses_bf16_mfma(const vitk_gemm_desc* desc);
 
 /* ------------------------------------------------------------------------------------------
  * Row normalisation.  rows = B*N tokens, d = d_model.

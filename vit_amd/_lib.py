@@ -44,6 +44,7 @@ SIGNATURES = {
 	"vitk_strerror": [I],
 	"vitk_version": [],
 	"vitk_gemm": [POINTER(GemmDesc), P],
+	"vitk_gemm_uses_bf16_mfma": [POINTER(GemmDesc)],
 	"vitk_layernorm_fwd": [P, P, P, P, P, P, P, P, I64, I64, FL, I, P],
 	"vitk_layernorm_bwd": [P, P, P, P, P, P, P, P, P, I64, I64, I, P],
 	"vitk_rmsnorm_fwd": [P, P, P, P, P, P, I64, I64, FL, I, I, P],

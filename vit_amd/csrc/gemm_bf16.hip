@@ -24,6 +24,8 @@ namespace {
 constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int TILE_BYTES = 128 * 64 * 2;  // 16 KiB, both layouts
 constexpr int STAGE_BYTES = 2 * TILE_BYTES;
+constexpr int CT_LD = 132;                                   // floats per row of the epilogue image (128 + 4 pad)
+constexpr int LDS_BYTES = 128 * CT_LD * 4;                   // 67,584 B >= the two operand stages (65,536 B)
 
 __device__ __forceinline__ int swz_k(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
 __device__ __forceinline__ int swz_mn(int krow, int chunk) {
@@ -119,6 +121,32 @@ struct BfArgs {
 	int vec4;                                    // epilogue may use 4-wide accesses
 };
 
+template <typename TOUT>
+__device__ __forceinline__ void store_frag(const BfArgs& a, int64_t m, int64_t nb, f32x4 v) {
+	const GemmDev& g = a.g;
+	if (a.splits > 1) {
+		float* c = reinterpret_cast<float*>(g.C) + m * g.ldc + nb;
+		if (nb + 3 < g.N) {
+			atomicAdd(c + 0, v[0]);
+			atomicAdd(c + 1, v[1]);
+			atomicAdd(c + 2, v[2]);
+			atomicAdd(c + 3, v[3]);
+		} else {
+			if (nb + 0 < g.N) atomicAdd(c + 0, v[0]);
+			if (nb + 1 < g.N) atomicAdd(c + 1, v[1]);
+			if (nb + 2 < g.N) atomicAdd(c + 2, v[2]);
+		}
+	} else if (a.vec4 && nb + 3 < g.N) {
+		const float f[4] = {v[0], v[1], v[2], v[3]};
+		epi_store4<bf16_t, TOUT>(g, m, nb, f);
+	} else {
+		if (nb + 0 < g.N) epi_store1<bf16_t, TOUT>(g, m, nb + 0, v[0]);
+		if (nb + 1 < g.N) epi_store1<bf16_t, TOUT>(g, m, nb + 1, v[1]);
+		if (nb + 2 < g.N) epi_store1<bf16_t, TOUT>(g, m, nb + 2, v[2]);
+		if (nb + 3 < g.N) epi_store1<bf16_t, TOUT>(g, m, nb + 3, v[3]);
+	}
+}
+
 template <int ALAYOUT, int BLAYOUT, bool PATCH, typename TOUT>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(BfArgs a) {
 	extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -192,35 +220,40 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(BfArgs a) {
 		__syncthreads();
 	}
 
-	// acc[i][j][r]: m = m0 + wm + 16 i + (lane & 15), n = n0 + wn + 16 j + 4 (lane >> 4) + r
+	// Epilogue through LDS: every lane drops its 16 accumulator fragments into a [128][128] float image of the
+	// output tile (rows padded by 16 bytes: the 8 lanes of a ds_write_b128 group hold 8 different rows), then the
+	// workgroup walks the image row-major, 4 consecutive columns per lane, so that the fused epilogue reads its
+	// residual / pre-activation operand and writes C in whole 128-byte lines.  The epilogue code exists once, in a
+	// runtime loop, and every index into acc[][] is a compile-time constant (a runtime index would move acc to scratch).
+	// acc[i][j][r]: m = wm + 16 i + (lane & 15), n = wn + 16 j + 4 (lane >> 4) + r
+	float* ct = reinterpret_cast<float*>(smem);
 #pragma unroll
-	for (int i = 0; i < 4; ++i) {
-		const int64_t m = m0 + wm + 16 * i + (lane & 15);
-		if (m >= g.M) continue;
+	for (int i = 0; i < 4; ++i)
 #pragma unroll
-		for (int j = 0; j < 4; ++j) {
-			const int64_t nb = n0 + wn + 16 * j + 4 * (lane >> 4);
-			if (nb >= g.N) continue;
-			if (a.splits > 1) {
-				float* c = reinterpret_cast<float*>(g.C) + m * g.ldc + nb;
-#pragma unroll
-				for (int r = 0; r < 4; ++r)
-					if (nb + r < g.N) atomicAdd(c + r, acc[i][j][r]);
-			} else if (a.vec4 && nb + 3 < g.N) {
-				const float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-				epi_store4<bf16_t, TOUT>(g, m, nb, v);
-			} else {
-#pragma unroll
-				for (int r = 0; r < 4; ++r)
-					if (nb + r < g.N) epi_store1<bf16_t, TOUT>(g, m, nb + r, acc[i][j][r]);
-			}
-		}
+		for (int j = 0; j < 4; ++j)
+			*reinterpret_cast<f32x4*>(ct + (wm + 16 * i + (lane & 15)) * CT_LD + wn + 16 * j + 4 * (lane >> 4)) = acc[i][j];
+	__syncthreads();
+	for (int it = 0; it < (BM * BN / 4) / 256; ++it) {
+		const int v = it * 256 + tid;
+		const int row = v >> 5, c4 = v & 31;
+		const int64_t m = m0 + row, nb = n0 + 4 * c4;
+		if (m >= g.M || nb >= g.N) continue;
+		const f32x4 val = *reinterpret_cast<const f32x4*>(ct + row * CT_LD + 4 * c4);
+		store_frag<TOUT>(a, m, nb, val);
 	}
 }
 
 template <int AL, int BL, bool PATCH>
 int launch(const BfArgs& a, int out_dtype, dim3 grid, hipStream_t st) {
-	const size_t lds = 2 * STAGE_BYTES;
+	const size_t lds = LDS_BYTES;
+	static bool attr_set[2] = {false, false};  // per template instantiation (function-local static)
+	const int oi = out_dtype == VITK_BF16 ? 0 : 1;
+	if (!attr_set[oi]) {
+		hipError_t e = oi == 0 ? hipFuncSetAttribute((const void*)gemm_bf16_kernel<AL, BL, PATCH, bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+							   : hipFuncSetAttribute((const void*)gemm_bf16_kernel<AL, BL, PATCH, float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+		if (e != hipSuccess) return VITK_ERR_HIP - (int)e;
+		attr_set[oi] = true;
+	}
 	if (out_dtype == VITK_BF16)
 		hipLaunchKernelGGL((gemm_bf16_kernel<AL, BL, PATCH, bf16_t>), grid, dim3(256), lds, st, a);
 	else

@@ -118,3 +118,8 @@ extern "C" int vitk_gemm(const vitk_gemm_desc* desc, void* stream) {
 	if (d.in_dtype == VITK_BF16 && vitk_gemm_bf16_ok(d)) return vitk_gemm_bf16(d, st);
 	return vitk_gemm_generic(d, st);
 }
+
+extern "C" int vitk_gemm_uses_bf16_mfma(const vitk_gemm_desc* desc) {
+	if (desc == nullptr) return 0;
+	return (desc->in_dtype == VITK_BF16 && vitk_gemm_bf16_ok(*desc)) ? 1 : 0;
+}

@@ -1,0 +1,171 @@
+"""Batch-sharded (data-parallel) training support: flat parameter / gradient buffers, bucketed gradient
+all-reduce overlapped with the backward pass, and the fused AdamW step.
+
+One process per GPU (torch.distributed, backend "nccl" = RCCL over xGMI).  Every rank holds a full
+replica; the only exchange per step is the sum of gradients.  Gradients live in ONE flat float32
+buffer laid out in parameter-registration order, so a bucket is a contiguous slice that is all-reduced
+in place (no packing copies).  Buckets are formed from the END of the buffer (the parameters whose
+gradients are produced first in the backward) and are launched from post-accumulate-grad hooks as
+soon as their last gradient lands, so the collectives run under the remaining backward kernels.
+xGMI is point-to-point: few large buckets (default 48 MiB) keep each ring step bandwidth-bound
+rather than latency-bound.
+
+The reference has no distributed code; the single-device semantics it defines (one optimizer step on
+the mean gradient of the global batch) are what the sharded step reproduces.
+"""
+import torch
+import torch.distributed as dist
+
+from . import _lib as L
+from . import ops
+
+
+def no_decay(name):
+	"""Parameter-group rule of the reference (utils.py:102-121 there): names containing 'bias', 'norm' or
+	'layerscale' get no weight decay.  (The block's LayerScale parameters are called '*_layer_scale', which
+	that substring test does not match, so they ARE decayed — reproduced as is.)"""
+	return ("bias" in name) or ("norm" in name) or ("layerscale" in name)
+
+
+class FlatModel:
+	"""Moves a module's parameters into one flat float32 buffer (and their .grad into another)."""
+
+	def __init__(self, module, bucket_bytes=48 << 20):
+		self.module = module
+		named = [(n, p) for n, p in module.named_parameters() if p.requires_grad]
+		assert named, "no trainable parameters"
+		dev = named[0][1].device
+		assert all(p.dtype == torch.float32 and p.device == dev for _, p in named), "flat buffers hold float32 parameters on one device"
+		# 64-element alignment keeps every parameter 256-byte aligned (16-byte vector loads in the kernels)
+		offs, total = [], 0
+		for _, p in named:
+			offs.append(total)
+			total += (p.numel() + 63) // 64 * 64
+		self.numel = total
+		self.param = torch.zeros(total, dtype=torch.float32, device=dev)
+		self.grad = torch.zeros(total, dtype=torch.float32, device=dev)
+		self.names = [n for n, _ in named]
+		self.params = [p for _, p in named]
+		self.offsets = offs
+		for (n, p), o in zip(named, offs):
+			self.param[o:o + p.numel()].copy_(p.data.reshape(-1))
+			p.data = self.param[o:o + p.numel()].view(p.shape)
+			p.grad = self.grad[o:o + p.numel()].view(p.shape)
+		# buckets: contiguous [start, end) ranges, formed from the end
+		self.buckets = []  # (start, end, [param indices])
+		end, idxs = total, []
+		for i in range(len(named) - 1, -1, -1):
+			idxs.append(i)
+			if (end - offs[i]) * 4 >= bucket_bytes or i == 0:
+				self.buckets.append((offs[i], end, idxs))
+				end, idxs = offs[i], []
+		self.bucket_of = {}
+		for b, (_, _, idxs) in enumerate(self.buckets):
+			for i in idxs:
+				self.bucket_of[i] = b
+
+	def zero_grad(self):
+		self.grad.zero_()
+		# autograd replaces .grad when it is None; keep the views attached
+		for p, o in zip(self.params, self.offsets):
+			if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * o:
+				p.grad = self.grad[o:o + p.numel()].view(p.shape)
+
+
+class GradSync:
+	"""Bucketed all-reduce(sum) of FlatModel.grad, launched from autograd hooks during backward."""
+
+	def __init__(self, flat, process_group=None):
+		self.flat = flat
+		self.group = process_group
+		self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+		self.pending = [0] * len(flat.buckets)
+		self.works = []
+		self.launched = []
+		if self.world > 1:
+			for i, p in enumerate(flat.params):
+				p.register_post_accumulate_grad_hook(self._make_hook(i))
+		self.reset()
+
+	def reset(self):
+		self.pending = [len(idxs) for _, _, idxs in self.flat.buckets]
+		self.works = []
+		self.launched = []
+
+	def _make_hook(self, i):
+		def hook(_param):
+			b = self.flat.bucket_of[i]
+			self.pending[b] -= 1
+			if self.pending[b] == 0:
+				self._launch(b)
+		return hook
+
+	def _launch(self, b):
+		start, end, _ = self.flat.buckets[b]
+		self.launched.append(b)
+		self.works.append(dist.all_reduce(self.flat.grad[start:end], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+	def finish(self):
+		"""Wait for the collectives of this step (launching any bucket whose hooks did not all fire, e.g. unused
+		parameters).  After this the flat gradient holds the SUM over ranks; the optimizer applies 1/world."""
+		if self.world > 1:
+			for b, n in enumerate(self.pending):
+				if n > 0:
+					self._launch(b)
+			for w in self.works:
+				w.wait()
+		self.reset()
+
+
+class FlatAdamW:
+	"""torch.optim.AdamW semantics (main.py:100 there) as ONE kernel over the flat buffers, which also writes the
+	bfloat16 copy of the parameters that the next forward's GEMMs read."""
+
+	def __init__(self, flat, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, decay_filter=no_decay, bf16_shadow=True):
+		self.flat = flat
+		self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
+		dev = flat.param.device
+		self.m = torch.zeros_like(flat.param)
+		self.v = torch.zeros_like(flat.param)
+		self.step_count = 0
+		mask = torch.ones(flat.numel, dtype=torch.uint8, device="cpu")
+		for n, p, o in zip(flat.names, flat.params, flat.offsets):
+			if decay_filter(n):
+				mask[o:o + p.numel()] = 0
+		self.wd_mask = mask.to(dev)
+		self.shadow = None
+		if bf16_shadow:
+			self.shadow = torch.empty(flat.numel, dtype=torch.bfloat16, device=dev)
+			L.check(L.load().vitk_cast(L.ptr(flat.param), L.ptr(self.shadow), flat.numel, L.F32, L.BF16, L.stream()))
+			for p, o in zip(flat.params, flat.offsets):
+				if p.dim() >= 2:
+					ops.register_shadow(p, self.shadow[o:o + p.numel()].view(p.shape))
+
+	def step(self, grad_scale=1.0):
+		self.step_count += 1
+		f = self.flat
+		L.check(L.load().vitk_adamw(L.ptr(f.param), L.ptr(f.grad), L.ptr(self.m), L.ptr(self.v), L.ptr(self.wd_mask), L.ptr(self.shadow), f.numel,
+			self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay, self.step_count, grad_scale, L.stream()))
+		if self.shadow is None:
+			ops.invalidate_casts()  # the kernel writes the parameters without bumping their version counters
+
+
+class Trainer:
+	"""zero_grad -> forward/backward (caller) -> step, with gradient sync when torch.distributed is initialised."""
+
+	def __init__(self, module, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, bucket_bytes=48 << 20):
+		if dist.is_initialized() and dist.get_world_size() > 1:
+			for p in module.parameters():
+				dist.broadcast(p.data, src=0)
+			for b in module.buffers():
+				dist.broadcast(b.data, src=0)
+		self.flat = FlatModel(module, bucket_bytes)
+		self.sync = GradSync(self.flat)
+		self.opt = FlatAdamW(self.flat, lr, betas, eps, weight_decay)
+
+	def zero_grad(self):
+		self.flat.zero_grad()
+
+	def step(self):
+		self.sync.finish()
+		self.opt.step(1.0 / self.sync.world)

@@ -44,11 +44,31 @@ def cast(t, dtype):
 _cast_cache = {}  # id(param) -> (weakref(param), key, cast copy)
 
 
+_shadows = {}  # id(param) -> (weakref(param), bf16 copy kept in sync by the optimizer kernel)
+
+
+def register_shadow(param, shadow_bf16):
+	"""Declare `shadow_bf16` to be a bfloat16 copy of `param` that its owner keeps up to date (the fused AdamW
+	kernel rewrites it with every step); weight_as() then returns it without casting."""
+	assert shadow_bf16.dtype == torch.bfloat16 and shadow_bf16.shape == param.shape and shadow_bf16.is_contiguous()
+	pid = id(param)
+	_shadows[pid] = (weakref.ref(param, lambda _r, pid=pid: _shadows.pop(pid, None)), shadow_bf16)
+
+
+def invalidate_casts():
+	"""Drop cached casts (call after modifying parameters through anything that does not bump their version)."""
+	_cast_cache.clear()
+
+
 def weight_as(w, dtype):
 	"""`w` in the compute dtype.  The cast of a parameter is cached until the parameter is modified
 	in place (optimizer step, load_state_dict), which bumps its version counter."""
 	if w.dtype == dtype and w.is_contiguous():
 		return w.detach()
+	if dtype == torch.bfloat16:
+		sh = _shadows.get(id(w))
+		if sh is not None and sh[0]() is w:
+			return sh[1]
 	key = (w._version, dtype, w.data_ptr())
 	hit = _cast_cache.get(id(w))
 	if hit is not None and hit[0]() is w and hit[1] == key:
@@ -76,6 +96,9 @@ def grad_as(g, like):
 # raw kernels
 # --------------------------------------------------------------------------------------------------
 
+GEMM_PROFILE = None  # set to a list to collect (kernel label, flops, start event, end event) per launch
+
+
 def gemm(A, B, C, M, N, K, lda, ldb, ldc, a_layout=L.K_MAJOR, b_layout=L.K_MAJOR, bias=None, epilogue=L.EPI_NONE, act=L.ACT_NONE,
 		aux=None, ld_aux=0, out2=None, ld_out2=0, gamma=None, accumulate=False, patch=None, tokens_per_image=0, pos=None):
 	"""C[M,N] (+)= epilogue(sum_k A(m,k) B(n,k)); see include/vitk.h for the operand layouts."""
@@ -98,7 +121,17 @@ def gemm(A, B, C, M, N, K, lda, ldb, ldc, a_layout=L.K_MAJOR, b_layout=L.K_MAJOR
 		assert t is None or (t.dtype == torch.float32 and t.is_contiguous())
 	assert aux is None or aux.dtype == A.dtype
 	assert out2 is None or out2.dtype == C.dtype
-	L.check(L.load().vitk_gemm(d, L.stream()))
+	lib = L.load()
+	if GEMM_PROFILE is None:
+		L.check(lib.vitk_gemm(d, L.stream()))
+		return C
+	# kernel timing for the roofline report: HIP events on the launch stream around this one launch
+	label = ("gemm_bf16_mfma" if lib.vitk_gemm_uses_bf16_mfma(d) else "gemm_generic") + f"<A{a_layout},B{b_layout}>"
+	e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+	e0.record()
+	L.check(lib.vitk_gemm(d, L.stream()))
+	e1.record()
+	GEMM_PROFILE.append((label, 2.0 * M * N * K, e0, e1))
 	return C
 
 
