@@ -1,5 +1,409 @@
-// bf16 MFMA attention kernels (placeholder until the MFMA path is enabled).
+// bf16 multi-head attention on the CDNA4 matrix cores for short sequences (head size 64, up to 256 keys):
+// the whole key/value set of one (batch, head) sits in LDS and the softmax of a query row is taken over
+// all keys at once in registers (no online rescaling is needed at ViT sequence lengths).
+//
+// One workgroup = one (batch, head); one wavefront = one 16-row tile of queries (forward, dQ) or keys (dK/dV).
+//
+// Forward, per wave (q on the MFMA lane):
+//   S^T[key][q] = K Q^T          A = K rows from LDS (ds_read_b128), B = Q rows straight from HBM
+//   P^T = softmax over keys      keys live in the accumulator registers + 4 lane groups: 2 shuffles per reduction
+//   O^T[d][q]  = V^T P^T         A = V^T by the transposing LDS read (ds_read_b64_tr_b16), B = P^T taken from the
+//                                accumulators of the first product with no lane movement (two 16-key tiles = one
+//                                32-deep k-step; the k -> key order of the A operand is permuted to match)
+// Backward is two kernels with the same structure, so that no gradient needs a cross-workgroup sum:
+//   dQ kernel (q on the lane):   S^T, dP^T = V dO^T, dS^T = P^T o (dP^T - delta) * scale, dQ^T = K^T dS^T
+//   dK/dV kernel (key on lane):  S = Q K^T, dP = dO V^T, dV^T = dO^T P, dK^T = Q^T dS; wave owns 16 keys, sums over all q
+//
+// LDS images are [row][64] bf16 with 128-byte rows and the 16-byte chunk index XOR-ed with (row & 7): conflict-free
+// both for the row reads (ds_read_b128) and for the transposing reads.
 #include "attention.h"
 
-bool vitk_attention_mfma_ok(const AttnArgs&, int) { return false; }
-int vitk_attention_mfma(const AttnArgs&, bool, hipStream_t) { return VITK_ERR_UNSUPPORTED; }
+namespace {
+
+constexpr int DH = 64;
+constexpr float LOG2E = 1.4426950408889634f;
+
+__device__ __forceinline__ int img_off(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
+
+// A/B fragment of 16 rows starting at row0, k-step s (32 of the 64 head columns): lane -> row (lane & 15), chunk 4 s + (lane >> 4)
+__device__ __forceinline__ bf16x8 row_frag(const char* img, int row0, int s, int lane) {
+	return *reinterpret_cast<const bf16x8*>(img + img_off(row0 + (lane & 15), 4 * s + (lane >> 4)));
+}
+
+// Transposed fragment: element j of lane (i = lane & 15, g = lane >> 4) = img[row(j)][col0 + i] with
+// row(j) = rowA + 4 g + j for j < 4 and rowB + 4 g + (j - 4) for j >= 4.
+__device__ __forceinline__ bf16x8 tr_frag(const char* img, int rowA, int rowB, int col0, int lane) {
+	const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
+	const int chunk = (col0 >> 3) + (p >> 1);
+	const int sub = (p & 1) << 3;
+	typedef s16x4 __attribute__((address_space(3))) * lds_ptr_t;
+	const int ra = rowA + 4 * g + q, rb = rowB + 4 * g + q;
+	s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr_t)(img + img_off(ra, chunk) + sub));
+	s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr_t)(img + img_off(rb, chunk) + sub));
+	union {
+		s16x4 h[2];
+		bf16x8 v;
+	} u;
+	u.h[0] = lo;
+	u.h[1] = hi;
+	return u.v;
+}
+
+__device__ __forceinline__ bf16x8 pack8(const f32x4& a, const f32x4& b) {
+	bf16x8 r;
+	r[0] = (bf16_t)a[0]; r[1] = (bf16_t)a[1]; r[2] = (bf16_t)a[2]; r[3] = (bf16_t)a[3];
+	r[4] = (bf16_t)b[0]; r[5] = (bf16_t)b[1]; r[6] = (bf16_t)b[2]; r[7] = (bf16_t)b[3];
+	return r;
+}
+
+__device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+
+// Stage rows [0, rows_pad) x 64 columns of a [*, ld] bf16 matrix into an LDS image; rows >= rows_valid are zero.
+__device__ __forceinline__ void stage_image(char* img, const bf16_t* src, int64_t ld, int rows_valid, int rows_pad) {
+	for (int idx = threadIdx.x; idx < rows_pad * 8; idx += blockDim.x) {
+		const int r = idx >> 3, c = idx & 7;
+		uint4 v = make_uint4(0, 0, 0, 0);
+		if (r < rows_valid) v = *reinterpret_cast<const uint4*>(src + (int64_t)r * ld + 8 * c);
+		*reinterpret_cast<uint4*>(img + img_off(r, c)) = v;
+	}
+}
+
+__device__ __forceinline__ float group_max(float v) {  // over the 4 lane groups that share (lane & 15)
+	v = fmaxf(v, __shfl_xor(v, 16, 64));
+	return fmaxf(v, __shfl_xor(v, 32, 64));
+}
+__device__ __forceinline__ float group_sum(float v) {
+	v += __shfl_xor(v, 16, 64);
+	return v + __shfl_xor(v, 32, 64);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// forward
+// ---------------------------------------------------------------------------------------------------------------
+template <int KT2>  // keys padded to 32 * KT2
+__global__ __launch_bounds__(1024) void attn_fwd_mfma_kernel(AttnArgs a) {
+	extern __shared__ __attribute__((aligned(16))) char smem[];
+	char* Ks = smem;
+	char* Vs = smem + KT2 * 32 * 128;
+	const int b = blockIdx.x / a.n_head, h = blockIdx.x % a.n_head;
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+	const int g = lane >> 4;
+	const bf16_t* kb = reinterpret_cast<const bf16_t*>(a.k) + (int64_t)b * a.Skv * a.ldk + h * DH;
+	const bf16_t* vb = reinterpret_cast<const bf16_t*>(a.v) + (int64_t)b * a.Skv * a.ldv + h * DH;
+	stage_image(Ks, kb, a.ldk, a.Skv, KT2 * 32);
+	stage_image(Vs, vb, a.ldv, a.Skv, KT2 * 32);
+	__syncthreads();
+	const float c = a.scale * LOG2E;
+	const int n_qtiles = (a.Sq + 15) >> 4;
+	for (int qt = wave; qt < n_qtiles; qt += nwaves) {
+		const int q = qt * 16 + (lane & 15);
+		const int qc = q < a.Sq ? q : a.Sq - 1;
+		const bf16_t* qp = reinterpret_cast<const bf16_t*>(a.q) + ((int64_t)b * a.Sq + qc) * a.ldq + h * DH + 8 * g;
+		const bf16x8 qf0 = *reinterpret_cast<const bf16x8*>(qp);
+		const bf16x8 qf1 = *reinterpret_cast<const bf16x8*>(qp + 32);
+		f32x4 st[2 * KT2];
+		float m = -INFINITY;
+#pragma unroll
+		for (int t = 0; t < 2 * KT2; ++t) {
+			f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+			acc = mfma16(row_frag(Ks, 16 * t, 0, lane), qf0, acc);
+			acc = mfma16(row_frag(Ks, 16 * t, 1, lane), qf1, acc);
+#pragma unroll
+			for (int r = 0; r < 4; ++r) {
+				if (16 * t + 4 * g + r >= a.Skv) acc[r] = -INFINITY;
+				m = fmaxf(m, acc[r]);
+			}
+			st[t] = acc;
+			__builtin_amdgcn_sched_barrier(0);  // keep the unrolled iterations in order: hoisting all LDS reads spills
+		}
+		m = group_max(m);
+		const float mc = m * c;
+		float l = 0.f;
+#pragma unroll
+		for (int t = 0; t < 2 * KT2; ++t)
+#pragma unroll
+			for (int r = 0; r < 4; ++r) {
+				const float p = __builtin_amdgcn_exp2f(st[t][r] * c - mc);
+				st[t][r] = p;
+				l += p;
+			}
+		l = group_sum(l);
+		f32x4 o[4];
+#pragma unroll
+		for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+		for (int u = 0; u < KT2; ++u) {
+			const bf16x8 pf = pack8(st[2 * u], st[2 * u + 1]);
+#pragma unroll
+			for (int dt = 0; dt < 4; ++dt) o[dt] = mfma16(tr_frag(Vs, 32 * u, 32 * u + 16, 16 * dt, lane), pf, o[dt]);
+			__builtin_amdgcn_sched_barrier(0);
+		}
+		if (q < a.Sq) {
+			const float inv = 1.f / l;
+			bf16_t* op = reinterpret_cast<bf16_t*>(a.out_w) + ((int64_t)b * a.Sq + q) * a.ldo + h * DH + 4 * g;
+#pragma unroll
+			for (int dt = 0; dt < 4; ++dt) {
+				bf16x4 ov;
+#pragma unroll
+				for (int r = 0; r < 4; ++r) ov[r] = (bf16_t)(o[dt][r] * inv);
+				*reinterpret_cast<bf16x4*>(op + 16 * dt) = ov;
+			}
+			if (g == 0) a.lse[((int64_t)b * a.n_head + h) * a.Sq + q] = m * a.scale + __logf(l);
+		}
+	}
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// backward: dQ (query on the lane)
+// ---------------------------------------------------------------------------------------------------------------
+template <int KT2>
+__global__ __launch_bounds__(1024) void attn_bwd_dq_mfma_kernel(AttnArgs a) {
+	extern __shared__ __attribute__((aligned(16))) char smem[];
+	char* Ks = smem;
+	char* Vs = smem + KT2 * 32 * 128;
+	const int b = blockIdx.x / a.n_head, h = blockIdx.x % a.n_head;
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+	const int g = lane >> 4;
+	const bf16_t* kb = reinterpret_cast<const bf16_t*>(a.k) + (int64_t)b * a.Skv * a.ldk + h * DH;
+	const bf16_t* vb = reinterpret_cast<const bf16_t*>(a.v) + (int64_t)b * a.Skv * a.ldv + h * DH;
+	stage_image(Ks, kb, a.ldk, a.Skv, KT2 * 32);
+	stage_image(Vs, vb, a.ldv, a.Skv, KT2 * 32);
+	__syncthreads();
+	const float c = a.scale * LOG2E;
+	const int n_qtiles = (a.Sq + 15) >> 4;
+	for (int qt = wave; qt < n_qtiles; qt += nwaves) {
+		const int q = qt * 16 + (lane & 15);
+		const int qc = q < a.Sq ? q : a.Sq - 1;
+		const int64_t qrow = (int64_t)b * a.Sq + qc;
+		const bf16_t* qp = reinterpret_cast<const bf16_t*>(a.q) + qrow * a.ldq + h * DH + 8 * g;
+		const bf16_t* gp = reinterpret_cast<const bf16_t*>(a.dout) + qrow * a.ldo + h * DH + 8 * g;
+		const bf16_t* op = reinterpret_cast<const bf16_t*>(a.out) + qrow * a.ldo + h * DH + 8 * g;
+		const bf16x8 qf0 = *reinterpret_cast<const bf16x8*>(qp), qf1 = *reinterpret_cast<const bf16x8*>(qp + 32);
+		const bf16x8 gf0 = *reinterpret_cast<const bf16x8*>(gp), gf1 = *reinterpret_cast<const bf16x8*>(gp + 32);
+		const bf16x8 of0 = *reinterpret_cast<const bf16x8*>(op), of1 = *reinterpret_cast<const bf16x8*>(op + 32);
+		float delta = 0.f;
+#pragma unroll
+		for (int j = 0; j < 8; ++j) delta += (float)gf0[j] * (float)of0[j] + (float)gf1[j] * (float)of1[j];
+		delta = group_sum(delta);
+		const float lse2 = a.lse[((int64_t)b * a.n_head + h) * a.Sq + qc] * LOG2E;
+		f32x4 dq[4];
+#pragma unroll
+		for (int dt = 0; dt < 4; ++dt) dq[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+		for (int u = 0; u < KT2; ++u) {
+			f32x4 ds[2];
+#pragma unroll
+			for (int hf = 0; hf < 2; ++hf) {
+				const int t = 2 * u + hf;
+				f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+				s = mfma16(row_frag(Ks, 16 * t, 0, lane), qf0, s);
+				s = mfma16(row_frag(Ks, 16 * t, 1, lane), qf1, s);
+				dp = mfma16(row_frag(Vs, 16 * t, 0, lane), gf0, dp);
+				dp = mfma16(row_frag(Vs, 16 * t, 1, lane), gf1, dp);
+#pragma unroll
+				for (int r = 0; r < 4; ++r) {
+					float p = __builtin_amdgcn_exp2f(s[r] * c - lse2);
+					if (16 * t + 4 * g + r >= a.Skv) p = 0.f;
+					ds[hf][r] = p * (dp[r] - delta) * a.scale;
+				}
+			}
+			const bf16x8 dsf = pack8(ds[0], ds[1]);
+#pragma unroll
+			for (int dt = 0; dt < 4; ++dt) dq[dt] = mfma16(tr_frag(Ks, 32 * u, 32 * u + 16, 16 * dt, lane), dsf, dq[dt]);
+		}
+		if (q < a.Sq) {
+			bf16_t* dqp = reinterpret_cast<bf16_t*>(a.dq) + ((int64_t)b * a.Sq + q) * a.lddq + h * DH + 4 * g;
+#pragma unroll
+			for (int dt = 0; dt < 4; ++dt) {
+				bf16x4 ov;
+#pragma unroll
+				for (int r = 0; r < 4; ++r) ov[r] = (bf16_t)dq[dt][r];
+				*reinterpret_cast<bf16x4*>(dqp + 16 * dt) = ov;
+			}
+		}
+	}
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// backward: dK, dV (key on the lane)
+// ---------------------------------------------------------------------------------------------------------------
+template <int QT2>  // queries padded to 32 * QT2
+__global__ __launch_bounds__(1024) void attn_bwd_dkv_mfma_kernel(AttnArgs a) {
+	extern __shared__ __attribute__((aligned(16))) char smem[];
+	constexpr int QP = QT2 * 32;
+	char* Qs = smem;
+	char* Gs = smem + QP * 128;
+	float* lse_s = reinterpret_cast<float*>(smem + 2 * QP * 128);
+	float* del_s = lse_s + QP;
+	const int b = blockIdx.x / a.n_head, h = blockIdx.x % a.n_head;
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+	const int g = lane >> 4;
+	const bf16_t* qb = reinterpret_cast<const bf16_t*>(a.q) + (int64_t)b * a.Sq * a.ldq + h * DH;
+	const bf16_t* gb = reinterpret_cast<const bf16_t*>(a.dout) + (int64_t)b * a.Sq * a.ldo + h * DH;
+	const bf16_t* ob = reinterpret_cast<const bf16_t*>(a.out) + (int64_t)b * a.Sq * a.ldo + h * DH;
+	stage_image(Qs, qb, a.ldq, a.Sq, QP);
+	// dO image + delta[q] = sum_d dO[q][d] O[q][d] (8 lanes per row, one 16-byte chunk each) + lse (in log2 units)
+	for (int idx = threadIdx.x; idx < QP * 8; idx += blockDim.x) {
+		const int r = idx >> 3, cc = idx & 7;
+		uint4 gv = make_uint4(0, 0, 0, 0), ov = make_uint4(0, 0, 0, 0);
+		if (r < a.Sq) {
+			gv = *reinterpret_cast<const uint4*>(gb + (int64_t)r * a.ldo + 8 * cc);
+			ov = *reinterpret_cast<const uint4*>(ob + (int64_t)r * a.ldo + 8 * cc);
+		}
+		*reinterpret_cast<uint4*>(Gs + img_off(r, cc)) = gv;
+		const bf16x8 g8 = *reinterpret_cast<const bf16x8*>(&gv), o8 = *reinterpret_cast<const bf16x8*>(&ov);
+		float d = 0.f;
+#pragma unroll
+		for (int j = 0; j < 8; ++j) d += (float)g8[j] * (float)o8[j];
+		d += __shfl_xor(d, 1, 64);
+		d += __shfl_xor(d, 2, 64);
+		d += __shfl_xor(d, 4, 64);
+		if (cc == 0) {
+			del_s[r] = d;
+			// padded queries: lse = +inf makes their probabilities exactly zero
+			lse_s[r] = r < a.Sq ? a.lse[((int64_t)b * a.n_head + h) * a.Sq + r] * LOG2E : INFINITY;
+		}
+	}
+	__syncthreads();
+	const float c = a.scale * LOG2E;
+	const int n_ktiles = (a.Skv + 15) >> 4;
+	for (int kt = wave; kt < n_ktiles; kt += nwaves) {
+		const int key = kt * 16 + (lane & 15);
+		const bool key_ok = key < a.Skv;
+		const int64_t krow = (int64_t)b * a.Skv + (key_ok ? key : a.Skv - 1);
+		const bf16_t* kp = reinterpret_cast<const bf16_t*>(a.k) + krow * a.ldk + h * DH + 8 * g;
+		const bf16_t* vp = reinterpret_cast<const bf16_t*>(a.v) + krow * a.ldv + h * DH + 8 * g;
+		const bf16x8 kf0 = *reinterpret_cast<const bf16x8*>(kp), kf1 = *reinterpret_cast<const bf16x8*>(kp + 32);
+		const bf16x8 vf0 = *reinterpret_cast<const bf16x8*>(vp), vf1 = *reinterpret_cast<const bf16x8*>(vp + 32);
+		f32x4 dk[4], dv[4];
+#pragma unroll
+		for (int dt = 0; dt < 4; ++dt) {
+			dk[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+			dv[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+		}
+#pragma unroll 1
+		for (int u = 0; u < QT2; ++u) {
+			f32x4 p[2], ds[2];
+#pragma unroll
+			for (int hf = 0; hf < 2; ++hf) {
+				const int t = 2 * u + hf;
+				f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+				s = mfma16(row_frag(Qs, 16 * t, 0, lane), kf0, s);
+				s = mfma16(row_frag(Qs, 16 * t, 1, lane), kf1, s);
+				dp = mfma16(row_frag(Gs, 16 * t, 0, lane), vf0, dp);
+				dp = mfma16(row_frag(Gs, 16 * t, 1, lane), vf1, dp);
+				const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_s + 16 * t + 4 * g);
+				const f32x4 d4 = *reinterpret_cast<const f32x4*>(del_s + 16 * t + 4 * g);
+#pragma unroll
+				for (int r = 0; r < 4; ++r) {
+					float pr = __builtin_amdgcn_exp2f(s[r] * c - l4[r]);
+					if (!key_ok) pr = 0.f;
+					p[hf][r] = pr;
+					ds[hf][r] = pr * (dp[r] - d4[r]) * a.scale;
+				}
+			}
+			const bf16x8 pf = pack8(p[0], p[1]);
+			const bf16x8 dsf = pack8(ds[0], ds[1]);
+#pragma unroll
+			for (int dt = 0; dt < 4; ++dt) {
+				dv[dt] = mfma16(tr_frag(Gs, 32 * u, 32 * u + 16, 16 * dt, lane), pf, dv[dt]);
+				dk[dt] = mfma16(tr_frag(Qs, 32 * u, 32 * u + 16, 16 * dt, lane), dsf, dk[dt]);
+			}
+		}
+		if (key_ok) {
+			bf16_t* dkp = reinterpret_cast<bf16_t*>(a.dk) + ((int64_t)b * a.Skv + key) * a.lddk + h * DH + 4 * g;
+			bf16_t* dvp = reinterpret_cast<bf16_t*>(a.dv) + ((int64_t)b * a.Skv + key) * a.lddv + h * DH + 4 * g;
+#pragma unroll
+			for (int dt = 0; dt < 4; ++dt) {
+				bf16x4 kv, vv;
+#pragma unroll
+				for (int r = 0; r < 4; ++r) {
+					kv[r] = (bf16_t)dk[dt][r];
+					vv[r] = (bf16_t)dv[dt][r];
+				}
+				*reinterpret_cast<bf16x4*>(dkp + 16 * dt) = kv;
+				*reinterpret_cast<bf16x4*>(dvp + 16 * dt) = vv;
+			}
+		}
+	}
+}
+
+template <int T2>
+int launch_fwd(const AttnArgs& a, hipStream_t st) {
+	const int nw = std::min(16, (a.Sq + 15) / 16);
+	const size_t lds = (size_t)2 * T2 * 32 * 128;
+	static bool attr = false;
+	if (!attr) {
+		hipError_t e = hipFuncSetAttribute((const void*)attn_fwd_mfma_kernel<T2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+		if (e != hipSuccess) return VITK_ERR_HIP - (int)e;
+		attr = true;
+	}
+	hipLaunchKernelGGL((attn_fwd_mfma_kernel<T2>), dim3((unsigned)(a.B * a.n_head)), dim3(64 * nw), lds, st, a);
+	VITK_CHECK_LAUNCH();
+	return VITK_OK;
+}
+template <int T2>
+int launch_dq(const AttnArgs& a, hipStream_t st) {
+	const int nw = std::min(16, (a.Sq + 15) / 16);
+	const size_t lds = (size_t)2 * T2 * 32 * 128;
+	static bool attr = false;
+	if (!attr) {
+		hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_dq_mfma_kernel<T2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+		if (e != hipSuccess) return VITK_ERR_HIP - (int)e;
+		attr = true;
+	}
+	hipLaunchKernelGGL((attn_bwd_dq_mfma_kernel<T2>), dim3((unsigned)(a.B * a.n_head)), dim3(64 * nw), lds, st, a);
+	VITK_CHECK_LAUNCH();
+	return VITK_OK;
+}
+template <int T2>
+int launch_dkv(const AttnArgs& a, hipStream_t st) {
+	const int nw = std::min(16, (a.Skv + 15) / 16);
+	const size_t lds = (size_t)2 * T2 * 32 * 128 + (size_t)2 * T2 * 32 * sizeof(float);
+	static bool attr = false;
+	if (!attr) {
+		hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_dkv_mfma_kernel<T2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+		if (e != hipSuccess) return VITK_ERR_HIP - (int)e;
+		attr = true;
+	}
+	hipLaunchKernelGGL((attn_bwd_dkv_mfma_kernel<T2>), dim3((unsigned)(a.B * a.n_head)), dim3(64 * nw), lds, st, a);
+	VITK_CHECK_LAUNCH();
+	return VITK_OK;
+}
+
+#define DISPATCH_T2(n, FN)                   \
+	switch (n) {                             \
+		case 1: return FN<1>(a, st);         \
+		case 2: return FN<2>(a, st);         \
+		case 3: return FN<3>(a, st);         \
+		case 4: return FN<4>(a, st);         \
+		case 5: return FN<5>(a, st);         \
+		case 6: return FN<6>(a, st);         \
+		case 7: return FN<7>(a, st);         \
+		case 8: return FN<8>(a, st);         \
+		default: return VITK_ERR_UNSUPPORTED; \
+	}
+
+int run_fwd(const AttnArgs& a, hipStream_t st) { DISPATCH_T2((a.Skv + 31) / 32, launch_fwd) }
+int run_dq(const AttnArgs& a, hipStream_t st) { DISPATCH_T2((a.Skv + 31) / 32, launch_dq) }
+int run_dkv(const AttnArgs& a, hipStream_t st) { DISPATCH_T2((a.Sq + 31) / 32, launch_dkv) }
+
+bool al16(const void* p) { return p == nullptr || vitk_aligned(p, 16); }
+bool al8(const void* p) { return p == nullptr || vitk_aligned(p, 8); }
+
+}  // namespace
+
+bool vitk_attention_mfma_ok(const AttnArgs& a, int dtype) {
+	if (dtype != VITK_BF16 || a.dh != DH) return false;
+	if (a.Skv > 256 || a.Sq > 256) return false;  // the dK/dV kernel keeps all queries in LDS, the others all keys
+	if ((a.ldq | a.ldk | a.ldv | a.ldo) % 8 != 0) return false;
+	if (a.dq != nullptr && ((a.lddq | a.lddk | a.lddv) % 4 != 0)) return false;
+	return al16(a.q) && al16(a.k) && al16(a.v) && al16(a.out) && al16(a.dout) && al8(a.out_w) && al8(a.dq) && al8(a.dk) && al8(a.dv);
+}
+
+int vitk_attention_mfma(const AttnArgs& a, bool bwd, hipStream_t st) {
+	if (!bwd) return run_fwd(a, st);
+	int rc = run_dq(a, st);
+	if (rc != VITK_OK) return rc;
+	return run_dkv(a, st);
+}
