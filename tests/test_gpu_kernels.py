@@ -23,7 +23,7 @@ def rnd(shape, dtype, dev, scale=1.0, seed=0):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (197, 384, 192), (300, 130, 72), (64, 1000, 768), (50, 10, 48), (512, 768, 3072), (33, 7, 5)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (197, 384, 192), (300, 130, 72), (64, 1000, 768), (50, 10, 48), (512, 768, 3072), (33, 7, 5), (1000, 264, 192), (257, 1032, 64)])
 @pytest.mark.parametrize("mode", ["fwd", "dgrad", "wgrad"])
 def test_gemm_layouts(gpu, dtype, M, N, K, mode):
 	from vit_amd import ops

@@ -70,7 +70,20 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, fl
 #pragma unroll
 	for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
 	if (col < N) {
-		for (int64_t m = (int64_t)blockIdx.y * 4 + wave; m < M; m += (int64_t)gridDim.y * 4) {
+		// 8 independent row loads in flight per lane; few workgroups per column strip keep the final float atomics
+		// (one per column per workgroup) far below the contended-atomic rate
+		const int64_t stride = (int64_t)gridDim.y * 4;
+		int64_t m = (int64_t)blockIdx.y * 4 + wave;
+		for (; m + 7 * stride < M; m += 8 * stride) {
+			float v[8][VEC];
+#pragma unroll
+			for (int u = 0; u < 8; ++u) load_vec<T, VEC>(x + (m + u * stride) * ld + col, v[u]);
+#pragma unroll
+			for (int u = 0; u < 8; ++u)
+#pragma unroll
+				for (int j = 0; j < VEC; ++j) acc[j] += v[u][j];
+		}
+		for (; m < M; m += stride) {
 			float v[VEC];
 			load_vec<T, VEC>(x + m * ld + col, v);
 #pragma unroll
@@ -94,7 +107,7 @@ int launch_colsum(const void* x, float* out, int64_t M, int64_t N, int64_t ld, h
 	constexpr int V = VecOf<T>::N;
 	const bool vec = (N % V == 0) && (ld % V == 0) && vitk_aligned(x, 16);
 	const int64_t strips = vitk_cdiv(N, 64 * (vec ? V : 1));
-	int64_t slabs = std::min<int64_t>(vitk_cdiv(M, 4), std::max<int64_t>(1, 2048 / strips));
+	int64_t slabs = std::min<int64_t>(vitk_cdiv(M, 32), std::max<int64_t>(1, 1024 / strips));
 	if (vec)
 		hipLaunchKernelGGL((colsum_kernel<T, V>), dim3((unsigned)strips, (unsigned)slabs), dim3(256), 0, st, (const T*)x, out, M, N, ld);
 	else

@@ -17,6 +17,8 @@
 //
 // The MFMA is issued as D = Wfrag x Xfrag so that a lane ends up with 4 consecutive n of one row m
 // (8-byte bf16 / 16-byte f32 stores and epilogue operand loads).
+#include <cstdlib>
+
 #include "gemm_common.h"
 
 namespace {
@@ -124,19 +126,7 @@ struct BfArgs {
 template <typename TOUT>
 __device__ __forceinline__ void store_frag(const BfArgs& a, int64_t m, int64_t nb, f32x4 v) {
 	const GemmDev& g = a.g;
-	if (a.splits > 1) {
-		float* c = reinterpret_cast<float*>(g.C) + m * g.ldc + nb;
-		if (nb + 3 < g.N) {
-			atomicAdd(c + 0, v[0]);
-			atomicAdd(c + 1, v[1]);
-			atomicAdd(c + 2, v[2]);
-			atomicAdd(c + 3, v[3]);
-		} else {
-			if (nb + 0 < g.N) atomicAdd(c + 0, v[0]);
-			if (nb + 1 < g.N) atomicAdd(c + 1, v[1]);
-			if (nb + 2 < g.N) atomicAdd(c + 2, v[2]);
-		}
-	} else if (a.vec4 && nb + 3 < g.N) {
+	if (a.vec4 && nb + 3 < g.N) {
 		const float f[4] = {v[0], v[1], v[2], v[3]};
 		epi_store4<bf16_t, TOUT>(g, m, nb, f);
 	} else {
@@ -233,6 +223,17 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(BfArgs a) {
 		for (int j = 0; j < 4; ++j)
 			*reinterpret_cast<f32x4*>(ct + (wm + 16 * i + (lane & 15)) * CT_LD + wn + 16 * j + 4 * (lane >> 4)) = acc[i][j];
 	__syncthreads();
+	if (a.splits > 1) {
+		// split-K partial sums: float atomics, one dword per lane on consecutive addresses
+		float* cbase = reinterpret_cast<float*>(g.C);
+		for (int it = 0; it < (BM * BN) / 256; ++it) {
+			const int v = it * 256 + tid;
+			const int row = v >> 7, col = v & 127;
+			const int64_t m = m0 + row, n = n0 + col;
+			if (m < g.M && n < g.N) atomicAdd(cbase + m * g.ldc + n, ct[row * CT_LD + col]);
+		}
+		return;
+	}
 	for (int it = 0; it < (BM * BN / 4) / 256; ++it) {
 		const int v = it * 256 + tid;
 		const int row = v >> 5, c4 = v & 31;
@@ -284,6 +285,8 @@ bool vitk_gemm_bf16_ok(const vitk_gemm_desc& d) {
 }
 
 int vitk_gemm_bf16(const vitk_gemm_desc& d, hipStream_t st) {
+	static const bool big_tiles = getenv("VITK_NO_BIG_TILE") == nullptr;  // debugging / A-B switch
+	if (big_tiles && vitk_gemm_bf16_256_ok(d)) return vitk_gemm_bf16_256(d, st);
 	BfArgs a{};
 	a.g = make_gemm_dev(d);
 	a.tiles_m = (int)vitk_cdiv(d.M, BM);
@@ -292,8 +295,8 @@ int vitk_gemm_bf16(const vitk_gemm_desc& d, hipStream_t st) {
 	const int64_t ktiles = vitk_cdiv(d.K, BK);
 	// split-K only for the plain float32-output form (weight gradients): few output tiles, long K
 	a.splits = 1;
-	if (d.out_dtype == VITK_F32 && d.epilogue == VITK_EPI_NONE && d.bias == nullptr && d.tokens_per_image == 0 && tiles < 384 && ktiles >= 16) {
-		int64_t s = std::min<int64_t>(vitk_cdiv(768, tiles), ktiles / 8);
+	if (d.out_dtype == VITK_F32 && d.epilogue == VITK_EPI_NONE && d.bias == nullptr && d.tokens_per_image == 0 && tiles <= 256 && ktiles >= 16) {
+		int64_t s = std::min<int64_t>(512 / tiles, ktiles / 8);  // two workgroups per CU
 		a.splits = (int)std::max<int64_t>(1, std::min<int64_t>(s, 64));
 	}
 	const int64_t kt_per = vitk_cdiv(ktiles, a.splits);
