@@ -53,23 +53,25 @@ __device__ __forceinline__ int64_t patch_offset(const GemmDev& g, int64_t m, int
 
 __device__ __forceinline__ int64_t out_row(const GemmDev& g, int64_t m) { return g.tpi > 0 ? m + m / g.tpi + 1 : m; }
 
-// Epilogue for ONE element.
-template <typename TIN, typename TOUT>
+// Epilogue for ONE element.  EPI >= 0 fixes the epilogue kind at compile time (dead branches vanish), -1 reads g.epilogue.
+template <typename TIN, typename TOUT, int EPI = -1, int ACT = -1>
 __device__ __forceinline__ void epi_store1(const GemmDev& g, int64_t m, int64_t n, float acc) {
+	const int epilogue = EPI >= 0 ? EPI : g.epilogue;
+	const int act = ACT >= 0 ? ACT : g.act;
 	float v = acc;
 	if (g.bias) v += g.bias[n];
 	if (g.tpi > 0 && g.pos) v += g.pos[(1 + m % g.tpi) * g.N + n];
 	const int64_t r = out_row(g, m);
-	if (g.epilogue == VITK_EPI_ACT) {
+	if (epilogue == VITK_EPI_ACT) {
 		if (g.out2) reinterpret_cast<TOUT*>(g.out2)[r * g.ld_out2 + n] = from_f32<TOUT>(v);
 		// the activation sees the pre-activation as it is stored (rounded to the output type)
-		v = act_apply(g.out2 ? round_to<TOUT>(v) : v, g.act);
-	} else if (g.epilogue == VITK_EPI_RESIDUAL) {
+		v = act_apply(g.out2 ? round_to<TOUT>(v) : v, act);
+	} else if (epilogue == VITK_EPI_RESIDUAL) {
 		const float res = to_f32<TIN>(reinterpret_cast<const TIN*>(g.aux)[r * g.ld_aux + n]);
 		v = res + (g.gamma ? g.gamma[n] : 1.f) * v;
-	} else if (g.epilogue == VITK_EPI_ACTGRAD) {
+	} else if (epilogue == VITK_EPI_ACTGRAD) {
 		const float u = to_f32<TIN>(reinterpret_cast<const TIN*>(g.aux)[r * g.ld_aux + n]);
-		v = v * act_deriv(u, g.act);
+		v = v * act_deriv(u, act);
 	}
 	TOUT* c = reinterpret_cast<TOUT*>(g.C) + r * g.ldc + n;
 	if (g.accumulate) v += to_f32<TOUT>(*c);
@@ -77,8 +79,10 @@ __device__ __forceinline__ void epi_store1(const GemmDev& g, int64_t m, int64_t 
 }
 
 // Epilogue for FOUR consecutive columns n0..n0+3 of row m (all in range, 8/16-byte aligned accesses).
-template <typename TIN, typename TOUT>
+template <typename TIN, typename TOUT, int EPI = -1, int ACT = -1>
 __device__ __forceinline__ void epi_store4(const GemmDev& g, int64_t m, int64_t n0, const float (&acc)[4]) {
+	const int epilogue = EPI >= 0 ? EPI : g.epilogue;
+	const int act = ACT >= 0 ? ACT : g.act;
 	float v[4] = {acc[0], acc[1], acc[2], acc[3]};
 	if (g.bias) {
 		float b[4];
@@ -93,25 +97,25 @@ __device__ __forceinline__ void epi_store4(const GemmDev& g, int64_t m, int64_t 
 		for (int j = 0; j < 4; ++j) v[j] += p[j];
 	}
 	const int64_t r = out_row(g, m);
-	if (g.epilogue == VITK_EPI_ACT) {
+	if (epilogue == VITK_EPI_ACT) {
 		if (g.out2) {
 			store_vec<TOUT, 4>(reinterpret_cast<TOUT*>(g.out2) + r * g.ld_out2 + n0, v);
 #pragma unroll
 			for (int j = 0; j < 4; ++j) v[j] = round_to<TOUT>(v[j]);
 		}
 #pragma unroll
-		for (int j = 0; j < 4; ++j) v[j] = act_apply(v[j], g.act);
-	} else if (g.epilogue == VITK_EPI_RESIDUAL) {
+		for (int j = 0; j < 4; ++j) v[j] = act_apply(v[j], act);
+	} else if (epilogue == VITK_EPI_RESIDUAL) {
 		float res[4], gm[4] = {1.f, 1.f, 1.f, 1.f};
 		load_vec<TIN, 4>(reinterpret_cast<const TIN*>(g.aux) + r * g.ld_aux + n0, res);
 		if (g.gamma) load_vec<float, 4>(g.gamma + n0, gm);
 #pragma unroll
 		for (int j = 0; j < 4; ++j) v[j] = res[j] + gm[j] * v[j];
-	} else if (g.epilogue == VITK_EPI_ACTGRAD) {
+	} else if (epilogue == VITK_EPI_ACTGRAD) {
 		float u[4];
 		load_vec<TIN, 4>(reinterpret_cast<const TIN*>(g.aux) + r * g.ld_aux + n0, u);
 #pragma unroll
-		for (int j = 0; j < 4; ++j) v[j] *= act_deriv(u[j], g.act);
+		for (int j = 0; j < 4; ++j) v[j] *= act_deriv(u[j], act);
 	}
 	TOUT* c = reinterpret_cast<TOUT*>(g.C) + r * g.ldc + n0;
 	if (g.accumulate) {
@@ -128,3 +132,5 @@ int vitk_gemm_bf16(const vitk_gemm_desc& d, hipStream_t st);  // returns VITK_ER
 bool vitk_gemm_bf16_ok(const vitk_gemm_desc& d);
 bool vitk_gemm_bf16_256_ok(const vitk_gemm_desc& d);  // large-tile LDS-DMA kernel (needs K % 64 == 0, M, N >= 256)
 int vitk_gemm_bf16_256(const vitk_gemm_desc& d, hipStream_t st);
+bool vitk_gemm_bf16_p_ok(const vitk_gemm_desc& d);    // persistent 256x256x64 LDS-DMA kernel (K % 64 == 0, M, N >= 256)
+int vitk_gemm_bf16_p(const vitk_gemm_desc& d, hipStream_t st);
