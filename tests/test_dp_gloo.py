@@ -1,0 +1,89 @@
+"""CPU, world_size 2, gloo: the flat-buffer bucketed gradient all-reduce of vit_amd.dp gives every rank the SUM of
+the per-rank gradients, i.e. (after the optimizer's 1/world scale) the gradient of the global batch, for any bucket
+size, including unused parameters.  The collective path is the same code that runs over RCCL on the GPUs."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+import torch.nn as nn
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, bucket_bytes, ret):
+	sys.path.insert(0, ROOT)
+	os.environ["MASTER_ADDR"] = "127.0.0.1"
+	os.environ["MASTER_PORT"] = str(port)
+	dist.init_process_group("gloo", rank=rank, world_size=world)
+	from vit_amd import dp
+	torch.manual_seed(0)
+	model = nn.Sequential(nn.Linear(16, 32), nn.GELU(), nn.Linear(32, 32), nn.GELU(), nn.Linear(32, 4))
+	unused = nn.Linear(3, 3)  # never used in forward: its bucket must still be reduced (zeros)
+	model.add_module("unused", unused)
+	flat = dp.FlatModel(model, bucket_bytes=bucket_bytes)
+	sync = dp.GradSync(flat)
+	g = torch.Generator().manual_seed(42)
+	x_all = torch.randn(8, 16, generator=g)
+	y_all = torch.randn(8, 4, generator=g)
+	xs, ys = x_all[rank::world], y_all[rank::world]
+	results = []
+	for step in range(2):
+		flat.zero_grad()
+		out = model[4](model[3](model[2](model[1](model[0](xs)))))
+		loss = ((out - ys) ** 2).sum()
+		loss.backward()
+		sync.finish()
+		results.append(flat.grad.clone())
+	# single-process reference on the global batch
+	ref = nn.Sequential(nn.Linear(16, 32), nn.GELU(), nn.Linear(32, 32), nn.GELU(), nn.Linear(32, 4))
+	torch.manual_seed(0)
+	ref = nn.Sequential(nn.Linear(16, 32), nn.GELU(), nn.Linear(32, 32), nn.GELU(), nn.Linear(32, 4))
+	out = ref(x_all)
+	((out - y_all) ** 2).sum().backward()
+	ok = True
+	for name, p in ref.named_parameters():
+		i = flat.names.index(name)
+		o = flat.offsets[i]
+		got = results[-1][o:o + p.numel()].view(p.shape)
+		ok = ok and torch.allclose(got, p.grad, rtol=1e-5, atol=1e-6)
+	n_buckets = len(flat.buckets)
+	all_views = all(p.grad.data_ptr() == flat.grad.data_ptr() + 4 * o for p, o in zip(flat.params, flat.offsets))
+	ret[rank] = (ok, n_buckets, all_views, torch.equal(results[0], results[1]))
+	dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("bucket_bytes", [1 << 30, 2048, 64])
+def test_bucketed_allreduce_two_ranks(bucket_bytes):
+	world = 2
+	port = 29500 + (os.getpid() % 1000) + {1 << 30: 0, 2048: 1, 64: 2}[bucket_bytes]
+	mgr = mp.Manager()
+	ret = mgr.dict()
+	mp.spawn(_worker, args=(world, port, bucket_bytes, ret), nprocs=world, join=True)
+	assert len(ret) == world
+	for rank in range(world):
+		ok, n_buckets, all_views, same = ret[rank]
+		assert ok, f"rank {rank}: reduced gradients differ from the global-batch gradients"
+		assert all_views, "parameter .grad tensors must stay views of the flat buffer"
+		assert same, "two identical steps must give identical reduced gradients"
+	if bucket_bytes == 64:
+		assert ret[0][1] >= 4
+	if bucket_bytes == 1 << 30:
+		assert ret[0][1] == 1
+
+
+def test_flat_model_layout():
+	sys.path.insert(0, ROOT)
+	from vit_amd import dp
+	m = nn.Sequential(nn.Linear(5, 7), nn.LayerNorm(7), nn.Linear(7, 3))
+	before = {k: v.clone() for k, v in m.state_dict().items()}
+	flat = dp.FlatModel(m, bucket_bytes=64)
+	for k, v in m.state_dict().items():
+		assert torch.equal(v, before[k])
+	assert all(o % 64 == 0 for o in flat.offsets)
+	covered = sorted((s, e) for s, e, _ in flat.buckets)
+	assert covered[0][0] == 0 and covered[-1][1] == flat.numel
+	assert all(covered[i][1] == covered[i + 1][0] for i in range(len(covered) - 1))
+	assert dp.no_decay("blocks.0.attn_norm.weight") and dp.no_decay("mlp.bias") and not dp.no_decay("blocks.0.attn_layer_scale")

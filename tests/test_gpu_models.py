@@ -139,3 +139,86 @@ def test_dropout_block_runs(gpu):
 	blk.train()
 	y_fused, _ = blk(x)
 	assert relerr(y_eval, y_fused) < 1e-5
+
+
+def make_cvt(c, gpu):
+	from vit_amd.layers import RMSNorm
+	from vit_amd.models import CvT
+
+	class Cfg:
+		pass
+	for k, v in c.items():
+		setattr(Cfg, k, tuple(v) if isinstance(v, list) else v)
+	Cfg.norm = RMSNorm if c["norm"] == "rmsnorm" else nn.LayerNorm
+	Cfg.dropout = 0.0
+	return CvT(Cfg()).to(gpu)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("mode", ["train", "eval"])
+def test_cvt_golden(gpu, mode, dtype):
+	"""CvT (conv token embedding + BatchNorm + conv-projection attention with Skv < Sq, down to a single key in stage 3)."""
+	from vit_amd import ops
+	g, meta = load_golden("cvt_small_" + mode)
+	model = make_cvt(meta["config"], gpu)
+	model.load_state_dict(sub(g, "sd"), strict=True)
+	model.train(mode == "train")
+	x = g["x"].to(gpu).requires_grad_(True)
+	y = g["y"].to(gpu)
+	with torch.autocast("cuda", dtype=torch.bfloat16, enabled=(dtype == torch.bfloat16)):
+		logits = model(x)
+		loss = ops.cross_entropy(logits.float(), y)
+	loss.backward()
+	tol, gtol = (2e-4, 1e-3) if dtype == torch.float32 else (3e-2, 8e-2)
+	assert relerr(logits, g["logits"]) < tol
+	assert relerr(loss, g["loss"]) < tol
+	assert relerr(x.grad, g["grad_x"]) < gtol
+	for k, p in model.named_parameters():
+		assert p.grad is not None, k
+		assert relerr(p.grad, g["grad/" + k]) < gtol, k
+	if mode == "train":  # BatchNorm running statistics after one training forward
+		sd = model.state_dict()
+		for k, v in sub(g, "sd_after").items():
+			assert relerr(sd[k], v) < (1e-4 if dtype == torch.float32 else 2e-2), k
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", ["s1", "s2", "s2_odd"])
+def test_conv_attention_golden(gpu, case, dtype):
+	from vit_amd.layers import ConvAttention
+	g, meta = load_golden("conv_attention")
+	c = sub(g, case)
+	dim, h, hw, stride = meta["cases"][case]
+	m = ConvAttention(dim, h, kernel_size=3, qkv_stride=stride, padding=1, dropout=0.0).to(gpu)
+	m.load_state_dict(sub(c, "sd"))
+	x = c["x"].to(gpu).to(dtype).requires_grad_(True)
+	y = m(x, hw, hw)
+	y.backward(c["dy"].to(gpu).to(dtype))
+	assert relerr(y, c["y"]) < TOL[dtype]
+	assert relerr(x.grad, c["dx"]) < GTOL[dtype]
+	for k, p in m.named_parameters():
+		assert relerr(p.grad, c["grad/" + k]) < GTOL[dtype], k
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", ["k7s4p2", "k3s2p1"])
+@pytest.mark.parametrize("mode", ["train", "eval"])
+def test_conv_embedding_golden(gpu, case, mode, dtype):
+	from vit_amd.layers import ConvEmbedding
+	g, meta = load_golden("conv_embedding")
+	c = sub(g, f"{case}/{mode}")
+	ci, co, k, s, p, hw = meta["cases"][case]
+	m = ConvEmbedding(ci, co, k, s, p).to(gpu)
+	m.load_state_dict(sub(c, "sd"))
+	m.train(mode == "train")
+	x = c["x"].to(gpu).to(dtype).requires_grad_(True)
+	y = m(x)
+	y.backward(c["dy"].to(gpu).to(dtype))
+	assert relerr(y, c["y"]) < TOL[dtype]
+	assert relerr(x.grad, c["dx"]) < GTOL[dtype]
+	for kk, pp in m.named_parameters():
+		assert relerr(pp.grad, c["grad/" + kk]) < GTOL[dtype], kk
+	if mode == "train":
+		sd = m.state_dict()
+		for kk, v in sub(c, "sd_after").items():
+			assert relerr(sd[kk], v) < TOL[dtype], kk

@@ -1,10 +1,385 @@
-// CvT kernels: depthwise convolution on token-major activations, im2col / col2im for the conv token
-// embedding, BatchNorm over token-major activations.
+// CvT kernels (all bandwidth-bound, channel-contiguous token-major activations [B, H*W, C]):
+//   depthwise k x k convolution of K and V (layers/attention.py:61-62,73-78 of the reference) — operating directly on
+//   tokens removes the four 'b (h w) c <-> b c h w' rearrange copies around it;
+//   im2col / col2im for the overlapping conv token embedding (layers/embeddings.py:21): the convolution itself is
+//   vitk_gemm on the gathered columns, whose [B*Ho*Wo, C_out] output IS the 'b (h w) c' token layout;
+//   BatchNorm over token-major activations (layers/embeddings.py:22) with batch statistics, running-stat update and
+//   backward.
 #include "vitk_common.h"
 
-extern "C" int vitk_dwconv_fwd(const void*, const void*, void*, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int, void*) { return VITK_ERR_UNSUPPORTED; }
-extern "C" int vitk_dwconv_bwd(const void*, const void*, const void*, void*, float*, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int, void*) { return VITK_ERR_UNSUPPORTED; }
-extern "C" int vitk_im2col(const void*, void*, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int, int, void*) { return VITK_ERR_UNSUPPORTED; }
-extern "C" int vitk_col2im(const void*, void*, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int, int, void*) { return VITK_ERR_UNSUPPORTED; }
-extern "C" int vitk_batchnorm_fwd(const void*, const float*, const float*, float*, float*, void*, float*, float*, int64_t, int64_t, float, float, int, int, void*) { return VITK_ERR_UNSUPPORTED; }
-extern "C" int vitk_batchnorm_bwd(const void*, const void*, const float*, const float*, const float*, void*, float*, float*, int64_t, int64_t, int, int, void*) { return VITK_ERR_UNSUPPORTED; }
+namespace {
+
+// ---- depthwise conv ----------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void dwconv_fwd_kernel(const T* __restrict__ x, const T* __restrict__ w, T* __restrict__ y, int64_t B, int H, int W, int C,
+	int ks, int stride, int pad, int Ho, int Wo) {
+	const int64_t n = B * Ho * Wo * C;
+	for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+		const int c = (int)(i % C);
+		int64_t t = i / C;
+		const int wo = (int)(t % Wo);
+		t /= Wo;
+		const int ho = (int)(t % Ho);
+		const int64_t b = t / Ho;
+		float acc = 0.f;
+		for (int kh = 0; kh < ks; ++kh) {
+			const int h = ho * stride - pad + kh;
+			if (h < 0 || h >= H) continue;
+			for (int kw = 0; kw < ks; ++kw) {
+				const int ww = wo * stride - pad + kw;
+				if (ww < 0 || ww >= W) continue;
+				acc += to_f32<T>(x[((b * H + h) * W + ww) * C + c]) * to_f32<T>(w[(c * ks + kh) * ks + kw]);
+			}
+		}
+		y[i] = from_f32<T>(acc);
+	}
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void dwconv_bwd_dx_kernel(const T* __restrict__ dy, const T* __restrict__ w, T* __restrict__ dx, int64_t B, int H, int W,
+	int C, int ks, int stride, int pad, int Ho, int Wo) {
+	const int64_t n = B * H * W * C;
+	for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+		const int c = (int)(i % C);
+		int64_t t = i / C;
+		const int ww = (int)(t % W);
+		t /= W;
+		const int h = (int)(t % H);
+		const int64_t b = t / H;
+		float acc = 0.f;
+		for (int kh = 0; kh < ks; ++kh) {
+			const int hn = h + pad - kh;
+			if (hn < 0 || hn % stride != 0) continue;
+			const int ho = hn / stride;
+			if (ho >= Ho) continue;
+			for (int kw = 0; kw < ks; ++kw) {
+				const int wn = ww + pad - kw;
+				if (wn < 0 || wn % stride != 0) continue;
+				const int wo = wn / stride;
+				if (wo >= Wo) continue;
+				acc += to_f32<T>(dy[((b * Ho + ho) * Wo + wo) * C + c]) * to_f32<T>(w[(c * ks + kh) * ks + kw]);
+			}
+		}
+		dx[i] = from_f32<T>(acc);
+	}
+}
+
+// dw[c, kh, kw] += sum over (b, ho, wo) of dy * x.  grid.x: channel blocks of 64, grid.y: slabs of output positions.
+template <typename T>
+__global__ __launch_bounds__(64) void dwconv_bwd_dw_kernel(const T* __restrict__ dy, const T* __restrict__ x, float* dw, int64_t B, int H, int W, int C, int ks,
+	int stride, int pad, int Ho, int Wo) {
+	const int c = blockIdx.x * 64 + threadIdx.x;
+	if (c >= C) return;
+	const int64_t npos = B * Ho * Wo;
+	float acc[25];  // ks <= 5
+	for (int j = 0; j < ks * ks; ++j) acc[j] = 0.f;
+	for (int64_t pidx = blockIdx.y; pidx < npos; pidx += gridDim.y) {
+		const int wo = (int)(pidx % Wo);
+		const int ho = (int)((pidx / Wo) % Ho);
+		const int64_t b = pidx / ((int64_t)Wo * Ho);
+		const float g = to_f32<T>(dy[pidx * C + c]);
+		for (int kh = 0; kh < ks; ++kh) {
+			const int h = ho * stride - pad + kh;
+			if (h < 0 || h >= H) continue;
+			for (int kw = 0; kw < ks; ++kw) {
+				const int ww = wo * stride - pad + kw;
+				if (ww < 0 || ww >= W) continue;
+				acc[kh * ks + kw] += g * to_f32<T>(x[((b * H + h) * W + ww) * C + c]);
+			}
+		}
+	}
+	for (int j = 0; j < ks * ks; ++j) atomicAdd(&dw[c * ks * ks + j], acc[j]);
+}
+
+// ---- im2col / col2im -----------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ int64_t src_index(int tokens_in, int64_t b, int c, int h, int w, int C, int H, int W) {
+	return tokens_in ? ((b * H + h) * W + w) * C + c : ((b * C + c) * H + h) * (int64_t)W + w;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void im2col_kernel(const T* __restrict__ x, T* __restrict__ cols, int64_t B, int C, int H, int W, int ks, int stride, int pad,
+	int Ho, int Wo, int tokens_in) {
+	const int K = C * ks * ks;
+	const int64_t n = B * Ho * Wo * K;
+	for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+		const int k = (int)(i % K);
+		int64_t t = i / K;
+		const int wo = (int)(t % Wo);
+		t /= Wo;
+		const int ho = (int)(t % Ho);
+		const int64_t b = t / Ho;
+		const int c = k / (ks * ks), r = k - c * ks * ks;
+		const int kh = r / ks, kw = r - kh * ks;
+		const int h = ho * stride - pad + kh, w = wo * stride - pad + kw;
+		T v = from_f32<T>(0.f);
+		if (h >= 0 && h < H && w >= 0 && w < W) v = x[src_index<T>(tokens_in, b, c, h, w, C, H, W)];
+		cols[i] = v;
+	}
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void col2im_kernel(const T* __restrict__ cols, T* __restrict__ dx, int64_t B, int C, int H, int W, int ks, int stride, int pad,
+	int Ho, int Wo, int tokens_in) {
+	const int K = C * ks * ks;
+	const int64_t n = B * C * H * W;
+	for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+		int c, h, w;
+		int64_t b;
+		if (tokens_in) {
+			c = (int)(i % C);
+			int64_t t = i / C;
+			w = (int)(t % W);
+			t /= W;
+			h = (int)(t % H);
+			b = t / H;
+		} else {
+			w = (int)(i % W);
+			int64_t t = i / W;
+			h = (int)(t % H);
+			t /= H;
+			c = (int)(t % C);
+			b = t / C;
+		}
+		float acc = 0.f;
+		for (int kh = 0; kh < ks; ++kh) {
+			const int hn = h + pad - kh;
+			if (hn < 0 || hn % stride != 0) continue;
+			const int ho = hn / stride;
+			if (ho >= Ho) continue;
+			for (int kw = 0; kw < ks; ++kw) {
+				const int wn = w + pad - kw;
+				if (wn < 0 || wn % stride != 0) continue;
+				const int wo = wn / stride;
+				if (wo >= Wo) continue;
+				acc += to_f32<T>(cols[((b * Ho + ho) * Wo + wo) * K + (c * ks + kh) * ks + kw]);
+			}
+		}
+		dx[i] = from_f32<T>(acc);
+	}
+}
+
+// ---- BatchNorm over x[rows, C] ------------------------------------------------------------------------------
+// pass A: out0[c] += sum_r f0, out1[c] += sum_r f1 with (f0, f1) = (x, -) | ((x-mean)^2, -) | (dy, dy * xhat)
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void bn_colreduce_kernel(const T* __restrict__ x, const T* __restrict__ dy, const float* __restrict__ mean,
+	const float* __restrict__ rstd, float* out0, float* out1, int64_t rows, int C) {
+	const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+	const int sub = threadIdx.x >> 6;
+	__shared__ float red0[4][64], red1[4][64];
+	float a0 = 0.f, a1 = 0.f;
+	if (c < C) {
+		const float mu = (MODE >= 1) ? mean[c] : 0.f;
+		const float rs = (MODE == 2) ? rstd[c] : 0.f;
+		for (int64_t r = (int64_t)blockIdx.y * 4 + sub; r < rows; r += (int64_t)gridDim.y * 4) {
+			const float v = to_f32<T>(x[r * C + c]);
+			if (MODE == 0) {
+				a0 += v;
+			} else if (MODE == 1) {
+				a0 += (v - mu) * (v - mu);
+			} else {
+				const float g = to_f32<T>(dy[r * C + c]);
+				a0 += g;
+				a1 += g * (v - mu) * rs;
+			}
+		}
+	}
+	red0[sub][threadIdx.x & 63] = a0;
+	red1[sub][threadIdx.x & 63] = a1;
+	__syncthreads();
+	if (sub == 0 && c < C) {
+		const int l = threadIdx.x;
+		atomicAdd(&out0[c], red0[0][l] + red0[1][l] + red0[2][l] + red0[3][l]);
+		if (MODE == 2) atomicAdd(&out1[c], red1[0][l] + red1[1][l] + red1[2][l] + red1[3][l]);
+	}
+}
+
+// sums -> mean (MODE 0) ; centred sums of squares -> rstd + running-stat update (MODE 1)
+template <int MODE>
+__global__ void bn_finalize_kernel(float* save_mean, float* save_rstd, float* running_mean, float* running_var, int64_t rows, int C, float eps, float momentum) {
+	const int c = blockIdx.x * blockDim.x + threadIdx.x;
+	if (c >= C) return;
+	if (MODE == 0) {
+		save_mean[c] = save_mean[c] / (float)rows;
+	} else {
+		const float var = save_rstd[c] / (float)rows;  // biased variance
+		save_rstd[c] = rsqrtf(var + eps);
+		const float unbiased = rows > 1 ? var * (float)rows / (float)(rows - 1) : var;
+		running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * save_mean[c];
+		running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+	}
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+	const float* __restrict__ mean, const float* __restrict__ rstd_or_var, T* __restrict__ y, int64_t n, int C, float eps, int use_var) {
+	for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+		const int c = (int)(i % C);
+		const float rs = use_var ? rsqrtf(rstd_or_var[c] + eps) : rstd_or_var[c];
+		y[i] = from_f32<T>((to_f32<T>(x[i]) - mean[c]) * rs * gamma[c] + beta[c]);
+	}
+}
+
+// training: dx = gamma * rstd * (dy - dbeta/n - xhat * dgamma/n); eval: dx = gamma * rstd * dy
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ x, const float* __restrict__ gamma,
+	const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ dgamma, const float* __restrict__ dbeta, T* __restrict__ dx,
+	int64_t n, int C, float inv_rows, int training) {
+	for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+		const int c = (int)(i % C);
+		const float g = to_f32<T>(dy[i]);
+		float v = g;
+		if (training) {
+			const float xhat = (to_f32<T>(x[i]) - mean[c]) * rstd[c];
+			v = g - dbeta[c] * inv_rows - xhat * dgamma[c] * inv_rows;
+		}
+		dx[i] = from_f32<T>(v * gamma[c] * rstd[c]);
+	}
+}
+
+// eval mode: expose the running statistics in the (mean, rstd) form the backward kernel reads
+__global__ void bn_eval_stats_kernel(const float* running_mean, const float* running_var, float* save_mean, float* save_rstd, int C, float eps) {
+	const int c = blockIdx.x * blockDim.x + threadIdx.x;
+	if (c < C) {
+		save_mean[c] = running_mean[c];
+		save_rstd[c] = rsqrtf(running_var[c] + eps);
+	}
+}
+
+inline dim3 colgrid(int64_t rows, int C) {
+	const unsigned gx = (unsigned)vitk_cdiv(C, 64);
+	const unsigned gy = (unsigned)std::max<int64_t>(1, std::min<int64_t>(vitk_cdiv(rows, 16), 1024 / gx));
+	return dim3(gx, gy);
+}
+
+}  // namespace
+
+#define DISPATCH_T(dtype, ...)             \
+	do {                                   \
+		if ((dtype) == VITK_F32) {         \
+			using T = float;               \
+			__VA_ARGS__;                   \
+		} else if ((dtype) == VITK_BF16) { \
+			using T = bf16_t;              \
+			__VA_ARGS__;                   \
+		} else                             \
+			return VITK_ERR_DTYPE;         \
+	} while (0)
+
+static bool conv_geom(int64_t H, int64_t W, int64_t ks, int64_t stride, int64_t pad, int64_t* Ho, int64_t* Wo) {
+	if (H <= 0 || W <= 0 || ks <= 0 || ks > 16 || stride <= 0 || pad < 0) return false;
+	*Ho = (H + 2 * pad - ks) / stride + 1;
+	*Wo = (W + 2 * pad - ks) / stride + 1;
+	return *Ho > 0 && *Wo > 0;
+}
+
+extern "C" int vitk_dwconv_fwd(const void* x, const void* w, void* y, int64_t B, int64_t H, int64_t W, int64_t C, int64_t ks, int64_t stride, int64_t pad,
+	int dtype, void* stream) {
+	VITK_REQUIRE(x && w && y, VITK_ERR_NULL);
+	int64_t Ho, Wo;
+	VITK_REQUIRE(B > 0 && C > 0 && conv_geom(H, W, ks, stride, pad, &Ho, &Wo), VITK_ERR_SHAPE);
+	DISPATCH_T(dtype, {
+		hipLaunchKernelGGL((dwconv_fwd_kernel<T>), dim3(vitk_stream_grid(B * Ho * Wo * C, 256)), dim3(256), 0, (hipStream_t)stream, (const T*)x, (const T*)w, (T*)y, B,
+			(int)H, (int)W, (int)C, (int)ks, (int)stride, (int)pad, (int)Ho, (int)Wo);
+		VITK_CHECK_LAUNCH();
+		return VITK_OK;
+	});
+}
+
+extern "C" int vitk_dwconv_bwd(const void* dy, const void* x, const void* w, void* dx, float* dw, int64_t B, int64_t H, int64_t W, int64_t C, int64_t ks,
+	int64_t stride, int64_t pad, int dtype, void* stream) {
+	VITK_REQUIRE(dy && x && w && dx && dw, VITK_ERR_NULL);
+	int64_t Ho, Wo;
+	VITK_REQUIRE(B > 0 && C > 0 && conv_geom(H, W, ks, stride, pad, &Ho, &Wo) && ks <= 5, VITK_ERR_SHAPE);
+	hipStream_t st = (hipStream_t)stream;
+	hipError_t e = hipMemsetAsync(dw, 0, (size_t)C * ks * ks * sizeof(float), st);
+	if (e != hipSuccess) return VITK_ERR_HIP - (int)e;
+	DISPATCH_T(dtype, {
+		hipLaunchKernelGGL((dwconv_bwd_dx_kernel<T>), dim3(vitk_stream_grid(B * H * W * C, 256)), dim3(256), 0, st, (const T*)dy, (const T*)w, (T*)dx, B, (int)H, (int)W,
+			(int)C, (int)ks, (int)stride, (int)pad, (int)Ho, (int)Wo);
+		VITK_CHECK_LAUNCH();
+		const unsigned gx = (unsigned)vitk_cdiv(C, 64);
+		const unsigned gy = (unsigned)std::max<int64_t>(1, std::min<int64_t>(B * Ho * Wo, 2048 / gx));
+		hipLaunchKernelGGL((dwconv_bwd_dw_kernel<T>), dim3(gx, gy), dim3(64), 0, st, (const T*)dy, (const T*)x, dw, B, (int)H, (int)W, (int)C, (int)ks, (int)stride,
+			(int)pad, (int)Ho, (int)Wo);
+		VITK_CHECK_LAUNCH();
+		return VITK_OK;
+	});
+}
+
+extern "C" int vitk_im2col(const void* x, void* cols, int64_t B, int64_t C, int64_t H, int64_t W, int64_t ks, int64_t stride, int64_t pad, int tokens_in, int dtype,
+	void* stream) {
+	VITK_REQUIRE(x && cols, VITK_ERR_NULL);
+	int64_t Ho, Wo;
+	VITK_REQUIRE(B > 0 && C > 0 && conv_geom(H, W, ks, stride, pad, &Ho, &Wo), VITK_ERR_SHAPE);
+	DISPATCH_T(dtype, {
+		hipLaunchKernelGGL((im2col_kernel<T>), dim3(vitk_stream_grid(B * Ho * Wo * C * ks * ks, 256)), dim3(256), 0, (hipStream_t)stream, (const T*)x, (T*)cols, B, (int)C,
+			(int)H, (int)W, (int)ks, (int)stride, (int)pad, (int)Ho, (int)Wo, tokens_in);
+		VITK_CHECK_LAUNCH();
+		return VITK_OK;
+	});
+}
+
+extern "C" int vitk_col2im(const void* cols, void* dx, int64_t B, int64_t C, int64_t H, int64_t W, int64_t ks, int64_t stride, int64_t pad, int tokens_in, int dtype,
+	void* stream) {
+	VITK_REQUIRE(cols && dx, VITK_ERR_NULL);
+	int64_t Ho, Wo;
+	VITK_REQUIRE(B > 0 && C > 0 && conv_geom(H, W, ks, stride, pad, &Ho, &Wo), VITK_ERR_SHAPE);
+	DISPATCH_T(dtype, {
+		hipLaunchKernelGGL((col2im_kernel<T>), dim3(vitk_stream_grid(B * C * H * W, 256)), dim3(256), 0, (hipStream_t)stream, (const T*)cols, (T*)dx, B, (int)C, (int)H,
+			(int)W, (int)ks, (int)stride, (int)pad, (int)Ho, (int)Wo, tokens_in);
+		VITK_CHECK_LAUNCH();
+		return VITK_OK;
+	});
+}
+
+extern "C" int vitk_batchnorm_fwd(const void* x, const float* gamma, const float* beta, float* running_mean, float* running_var, void* y, float* save_mean,
+	float* save_rstd, int64_t rows, int64_t C, float eps, float momentum, int training, int dtype, void* stream) {
+	VITK_REQUIRE(x && gamma && beta && running_mean && running_var && y, VITK_ERR_NULL);
+	VITK_REQUIRE(rows > 0 && C > 0 && C < (1 << 30), VITK_ERR_SHAPE);
+	hipStream_t st = (hipStream_t)stream;
+	const int64_t n = rows * C;
+	if (!training) {
+		if (save_mean && save_rstd) hipLaunchKernelGGL(bn_eval_stats_kernel, dim3((unsigned)vitk_cdiv(C, 256)), dim3(256), 0, st, running_mean, running_var, save_mean, save_rstd, (int)C, eps);
+		DISPATCH_T(dtype, {
+			hipLaunchKernelGGL((bn_apply_kernel<T>), dim3(vitk_stream_grid(n, 256)), dim3(256), 0, st, (const T*)x, gamma, beta, running_mean, running_var, (T*)y, n, (int)C,
+				eps, 1);
+			VITK_CHECK_LAUNCH();
+			return VITK_OK;
+		});
+	}
+	VITK_REQUIRE(save_mean && save_rstd, VITK_ERR_NULL);
+	hipError_t e = hipMemsetAsync(save_mean, 0, (size_t)C * sizeof(float), st);
+	if (e == hipSuccess) e = hipMemsetAsync(save_rstd, 0, (size_t)C * sizeof(float), st);
+	if (e != hipSuccess) return VITK_ERR_HIP - (int)e;
+	const dim3 cg = colgrid(rows, (int)C);
+	const unsigned fg = (unsigned)vitk_cdiv(C, 256);
+	DISPATCH_T(dtype, {
+		hipLaunchKernelGGL((bn_colreduce_kernel<T, 0>), cg, dim3(256), 0, st, (const T*)x, (const T*)nullptr, nullptr, nullptr, save_mean, nullptr, rows, (int)C);
+		hipLaunchKernelGGL((bn_finalize_kernel<0>), dim3(fg), dim3(256), 0, st, save_mean, save_rstd, running_mean, running_var, rows, (int)C, eps, momentum);
+		hipLaunchKernelGGL((bn_colreduce_kernel<T, 1>), cg, dim3(256), 0, st, (const T*)x, (const T*)nullptr, save_mean, nullptr, save_rstd, nullptr, rows, (int)C);
+		hipLaunchKernelGGL((bn_finalize_kernel<1>), dim3(fg), dim3(256), 0, st, save_mean, save_rstd, running_mean, running_var, rows, (int)C, eps, momentum);
+		hipLaunchKernelGGL((bn_apply_kernel<T>), dim3(vitk_stream_grid(n, 256)), dim3(256), 0, st, (const T*)x, gamma, beta, save_mean, save_rstd, (T*)y, n, (int)C, eps, 0);
+		VITK_CHECK_LAUNCH();
+		return VITK_OK;
+	});
+}
+
+extern "C" int vitk_batchnorm_bwd(const void* dy, const void* x, const float* gamma, const float* save_mean, const float* save_rstd, void* dx, float* dgamma,
+	float* dbeta, int64_t rows, int64_t C, int training, int dtype, void* stream) {
+	VITK_REQUIRE(dy && x && gamma && save_mean && save_rstd && dx && dgamma && dbeta, VITK_ERR_NULL);
+	VITK_REQUIRE(rows > 0 && C > 0 && C < (1 << 30), VITK_ERR_SHAPE);
+	hipStream_t st = (hipStream_t)stream;
+	const int64_t n = rows * C;
+	hipError_t e = hipMemsetAsync(dgamma, 0, (size_t)C * sizeof(float), st);
+	if (e == hipSuccess) e = hipMemsetAsync(dbeta, 0, (size_t)C * sizeof(float), st);
+	if (e != hipSuccess) return VITK_ERR_HIP - (int)e;
+	const dim3 cg = colgrid(rows, (int)C);
+	DISPATCH_T(dtype, {
+		hipLaunchKernelGGL((bn_colreduce_kernel<T, 2>), cg, dim3(256), 0, st, (const T*)x, (const T*)dy, save_mean, save_rstd, dbeta, dgamma, rows, (int)C);
+		hipLaunchKernelGGL((bn_bwd_apply_kernel<T>), dim3(vitk_stream_grid(n, 256)), dim3(256), 0, st, (const T*)dy, (const T*)x, gamma, save_mean, save_rstd, dgamma, dbeta,
+			(T*)dx, n, (int)C, 1.0f / (float)rows, training);
+		VITK_CHECK_LAUNCH();
+		return VITK_OK;
+	});
+}

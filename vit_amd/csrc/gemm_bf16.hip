@@ -286,11 +286,6 @@ bool vitk_gemm_bf16_ok(const vitk_gemm_desc& d) {
 
 int vitk_gemm_bf16(const vitk_gemm_desc& d, hipStream_t st) {
 	static const bool big_tiles = getenv("VITK_NO_BIG_TILE") == nullptr;  // debugging / A-B switch
-	static const bool persistent = getenv("VITK_NO_PERSISTENT") == nullptr;
-	if (big_tiles && persistent && vitk_gemm_bf16_p_ok(d)) {
-		const int rc = vitk_gemm_bf16_p(d, st);
-		if (rc != VITK_ERR_UNSUPPORTED) return rc;
-	}
 	if (big_tiles && vitk_gemm_bf16_256_ok(d)) return vitk_gemm_bf16_256(d, st);
 	BfArgs a{};
 	a.g = make_gemm_dev(d);

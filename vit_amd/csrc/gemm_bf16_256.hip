@@ -80,7 +80,6 @@ struct BigArgs {
 	GemmDev g;
 	int tiles_m, tiles_n, splits, k_per_split;
 	int vec4;
-	int dbg;  // diagnostic switches (VITK_DBG): 1 = no LDS-DMA inside the loop, 2 = no MFMA, 4 = no fragment reads in loop
 };
 
 template <typename TOUT>
@@ -97,7 +96,7 @@ __device__ __forceinline__ void store4(const BigArgs& a, int64_t m, int64_t nb, 
 	}
 }
 
-template <int ALAYOUT, int BLAYOUT, typename TOUT, int DBG = 0>
+template <int ALAYOUT, int BLAYOUT, typename TOUT>
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_256_kernel(BigArgs a) {
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 	const GemmDev& g = a.g;
@@ -140,7 +139,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_256_kernel(BigArgs a) {
 	for (int t = 0; t < nt; ++t) {
 		const char* sa = smem + (t & 1) * STAGE_BYTES;
 		const char* sb = sa + TILE_BYTES;
-		if (t + 1 < nt && !(DBG & 1)) {
+		if (t + 1 < nt) {
 			char* da = smem + ((t + 1) & 1) * STAGE_BYTES;
 			const int k0 = k_begin + (t + 1) * BK;
 			stage_tile<ALAYOUT>(da, A, g.lda, m0, g.M, k0, wave, lane);
@@ -156,20 +155,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_256_kernel(BigArgs a) {
 #pragma unroll
 			for (int i = 0; i < 8; ++i)
 #pragma unroll
-				for (int j = 0; j < 4; ++j) {
-					if (!(DBG & 2))
-						acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], acc[i][j], 0, 0, 0);
-					else
-						asm volatile("" ::"v"(wf[j]), "v"(xf[i]));
-				}
+				for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], acc[i][j], 0, 0, 0);
 		}
 		__syncthreads();  // next stage landed (vmcnt(0) drained by the fence) and everyone is done with this one
 	}
 
-	if (DBG & 8) {  // diagnostic: no epilogue (keep one accumulator live)
-		if (acc[0][0][0] == 123.456f) reinterpret_cast<float*>(g.C)[0] = 1.f;
-		return;
-	}
 	// epilogue through LDS, 128 rows at a time
 	float* ct = reinterpret_cast<float*>(smem);
 #pragma unroll
@@ -234,8 +224,6 @@ bool vitk_gemm_bf16_256_ok(const vitk_gemm_desc& d) {
 int vitk_gemm_bf16_256(const vitk_gemm_desc& d, hipStream_t st) {
 	BigArgs a{};
 	a.g = make_gemm_dev(d);
-	static const int dbg = getenv("VITK_DBG") ? atoi(getenv("VITK_DBG")) : 0;
-	a.dbg = dbg;
 	a.tiles_m = (int)vitk_cdiv(d.M, BM);
 	a.tiles_n = (int)vitk_cdiv(d.N, BN);
 	const int64_t tiles = (int64_t)a.tiles_m * a.tiles_n;
@@ -258,15 +246,6 @@ int vitk_gemm_bf16_256(const vitk_gemm_desc& d, hipStream_t st) {
 		if (e != hipSuccess) return VITK_ERR_HIP - (int)e;
 	}
 	dim3 grid((unsigned)tiles, (unsigned)a.splits);
-	if (a.dbg != 0 && d.a_layout == VITK_K_MAJOR && d.b_layout == VITK_K_MAJOR && d.out_dtype == VITK_BF16) {
-		// diagnostic builds of the K-major x K-major kernel (results are wrong by design)
-#define DBG_CASE(n) case n: hipFuncSetAttribute((const void*)gemm_bf16_256_kernel<0, 0, bf16_t, n>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES); \
-		hipLaunchKernelGGL((gemm_bf16_256_kernel<0, 0, bf16_t, n>), grid, dim3(NTHREADS), LDS_BYTES, st, a); break;
-		switch (a.dbg) { DBG_CASE(1) DBG_CASE(2) DBG_CASE(3) DBG_CASE(8) DBG_CASE(9) DBG_CASE(10) DBG_CASE(11) default: break; }
-#undef DBG_CASE
-		VITK_CHECK_LAUNCH();
-		return VITK_OK;
-	}
 	if (d.a_layout == VITK_K_MAJOR && d.b_layout == VITK_K_MAJOR) return launch<VITK_K_MAJOR, VITK_K_MAJOR>(a, d.out_dtype, grid, st);
 	if (d.a_layout == VITK_K_MAJOR && d.b_layout == VITK_MN_MAJOR) return launch<VITK_K_MAJOR, VITK_MN_MAJOR>(a, d.out_dtype, grid, st);
 	if (d.a_layout == VITK_MN_MAJOR && d.b_layout == VITK_MN_MAJOR) return launch<VITK_MN_MAJOR, VITK_MN_MAJOR>(a, d.out_dtype, grid, st);

@@ -711,3 +711,177 @@ def dropout(x, p):
 	_dropout_calls[0] += 1
 	seed = (torch.initial_seed() * 0x9E3779B1 + _dropout_calls[0] * 0x85EBCA77) & 0xFFFFFFFFFFFFFFFF
 	return DropoutFn.apply(x, float(p), seed)
+
+
+# --------------------------------------------------------------------------------------------------
+# CvT: conv token embedding, conv-projection attention, mean pool
+# --------------------------------------------------------------------------------------------------
+
+def _conv_out(n, ks, stride, pad):
+	return (n + 2 * pad - ks) // stride + 1
+
+
+class ConvEmbedFn(torch.autograd.Function):
+	"""Conv2d(bias=False) -> BatchNorm2d -> tokens (layers/embeddings.py:24-28 of the reference) as
+	im2col gather + MFMA GEMM + token-major BatchNorm.  Input: NCHW, or token-major [B, H*W, C] with hw=(H, W)."""
+
+	@staticmethod
+	def forward(ctx, x, conv_w, bn_w, bn_b, running_mean, running_var, cfg):
+		ks, stride, pad, eps, momentum, training, hw = cfg
+		L.require_gpu(x, conv_w)
+		lib = L.load()
+		dt = compute_dtype(x)
+		xc = cast(x, dt)
+		if hw is None:
+			Bn, C, H, W = xc.shape
+			tokens_in = 0
+		else:
+			Bn, S, C = xc.shape
+			H, W = hw
+			assert S == H * W
+			tokens_in = 1
+		Ho, Wo = _conv_out(H, ks, stride, pad), _conv_out(W, ks, stride, pad)
+		Cout = conv_w.shape[0]
+		K = C * ks * ks
+		rows = Bn * Ho * Wo
+		dtc = L.dtype_code(dt)
+		cols = torch.empty((rows, K), dtype=dt, device=x.device)
+		L.check(lib.vitk_im2col(L.ptr(xc), L.ptr(cols), Bn, C, H, W, ks, stride, pad, tokens_in, dtc, L.stream()))
+		w2 = weight_as(conv_w, dt).reshape(Cout, K)
+		y0 = linear_fwd(cols, w2)
+		y = torch.empty_like(y0)
+		save_mean = torch.empty(Cout, dtype=torch.float32, device=x.device)
+		save_rstd = torch.empty(Cout, dtype=torch.float32, device=x.device)
+		L.check(lib.vitk_batchnorm_fwd(L.ptr(y0), L.ptr(f32(bn_w)), L.ptr(f32(bn_b)), L.ptr(running_mean), L.ptr(running_var), L.ptr(y),
+			L.ptr(save_mean), L.ptr(save_rstd), rows, Cout, eps, momentum, int(training), dtc, L.stream()))
+		ctx.save_for_backward(cols, y0, save_mean, save_rstd, conv_w, bn_w)
+		ctx.meta = (x.shape, x.dtype, bn_b, cfg, dt, (Bn, C, H, W, Ho, Wo, tokens_in))
+		return y.reshape(Bn, Ho * Wo, Cout)
+
+	@staticmethod
+	def backward(ctx, dy):
+		cols, y0, save_mean, save_rstd, conv_w, bn_w = ctx.saved_tensors
+		xshape, xdtype, bn_b, cfg, dt, (Bn, C, H, W, Ho, Wo, tokens_in) = ctx.meta
+		ks, stride, pad, eps, momentum, training, hw = cfg
+		lib = L.load()
+		dtc = L.dtype_code(dt)
+		rows, Cout = y0.shape
+		dy2 = _flat(cast(dy, dt))
+		dy0 = torch.empty_like(y0)
+		dgamma = torch.empty(Cout, dtype=torch.float32, device=dy.device)
+		dbeta = torch.empty(Cout, dtype=torch.float32, device=dy.device)
+		L.check(lib.vitk_batchnorm_bwd(L.ptr(dy2), L.ptr(y0), L.ptr(f32(bn_w)), L.ptr(save_mean), L.ptr(save_rstd), L.ptr(dy0), L.ptr(dgamma), L.ptr(dbeta),
+			rows, Cout, int(training), dtc, L.stream()))
+		dw = linear_wgrad(dy0, cols).reshape(conv_w.shape)
+		dx = None
+		if ctx.needs_input_grad[0]:
+			w2 = weight_as(conv_w, dt).reshape(Cout, -1)
+			dcols = linear_dgrad(dy0, w2)
+			dx = torch.empty(xshape, dtype=dt, device=dy.device)
+			L.check(lib.vitk_col2im(L.ptr(dcols), L.ptr(dx), Bn, C, H, W, ks, stride, pad, tokens_in, dtc, L.stream()))
+			if dx.dtype != xdtype:
+				dx = cast(dx, xdtype)
+		return dx, grad_as(dw, conv_w), grad_as(dgamma, bn_w), grad_as(dbeta, bn_b), None, None, None
+
+
+def conv_embedding(mod, x, hw=None):
+	"""Forward of a layers.embeddings.ConvEmbedding module (parameters in mod.conv / mod.norm)."""
+	conv, bn = mod.conv, mod.norm
+	ks, stride, pad = conv.kernel_size[0], conv.stride[0], conv.padding[0]
+	assert conv.kernel_size[0] == conv.kernel_size[1] and conv.bias is None and conv.groups == 1
+	training = bn.training or not bn.track_running_stats
+	if bn.momentum is None:
+		raise NotImplementedError("BatchNorm2d(momentum=None) (cumulative average) is not supported")
+	if training and bn.track_running_stats:
+		bn.num_batches_tracked += 1
+	return ConvEmbedFn.apply(x, conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var, (ks, stride, pad, bn.eps, bn.momentum, training, hw))
+
+
+def dwconv_fwd(x, w, Bn, H, W, C, ks, stride, pad):
+	Ho, Wo = _conv_out(H, ks, stride, pad), _conv_out(W, ks, stride, pad)
+	y = torch.empty((Bn * Ho * Wo, C), dtype=x.dtype, device=x.device)
+	L.check(L.load().vitk_dwconv_fwd(L.ptr(x), L.ptr(w), L.ptr(y), Bn, H, W, C, ks, stride, pad, L.dtype_code(x.dtype), L.stream()))
+	return y, Ho * Wo
+
+
+def dwconv_bwd(dy, x, w, Bn, H, W, C, ks, stride, pad):
+	dx = torch.empty_like(x)
+	dw = torch.empty((C, 1, ks, ks), dtype=torch.float32, device=x.device)
+	L.check(L.load().vitk_dwconv_bwd(L.ptr(dy), L.ptr(x), L.ptr(w), L.ptr(dx), L.ptr(dw), Bn, H, W, C, ks, stride, pad, L.dtype_code(x.dtype), L.stream()))
+	return dx, dw
+
+
+class ConvAttentionFn(torch.autograd.Function):
+	"""CvT attention (layers/attention.py:67-93 of the reference): q/k/v Linear (with bias), depthwise conv on K and V
+	applied directly to token-major activations, attention with Skv <= Sq, output projection."""
+
+	@staticmethod
+	def forward(ctx, x, wq, bq, wk, bk, wv, bv, ck, cv, wo, bo, cfg):
+		H, W, n_head, ks, stride, pad = cfg
+		L.require_gpu(x, wq)
+		dt = compute_dtype(x)
+		Bn, S, C = x.shape
+		assert S == H * W
+		dh = C // n_head
+		x2 = _flat(cast(x, dt))
+		q = linear_fwd(x2, weight_as(wq, dt), f32(bq))
+		k0 = linear_fwd(x2, weight_as(wk, dt), f32(bk))
+		v0 = linear_fwd(x2, weight_as(wv, dt), f32(bv))
+		ckc, cvc = weight_as(ck, dt), weight_as(cv, dt)
+		k1, Skv = dwconv_fwd(k0, ckc, Bn, H, W, C, ks, stride, pad)
+		v1, _ = dwconv_fwd(v0, cvc, Bn, H, W, C, ks, stride, pad)
+		o, lse = attention_fwd(q, k1, v1, Bn, n_head, S, Skv, dh)
+		y = linear_fwd(o, weight_as(wo, dt), f32(bo))
+		ctx.save_for_backward(x2, q, k0, v0, k1, v1, o, lse, wq, wk, wv, ck, cv, wo)
+		ctx.meta = (x.shape, x.dtype, (bq, bk, bv, bo), cfg, dt, Skv)
+		return y.reshape(Bn, S, C)
+
+	@staticmethod
+	def backward(ctx, dy):
+		x2, q, k0, v0, k1, v1, o, lse, wq, wk, wv, ck, cv, wo = ctx.saved_tensors
+		(Bn, S, C), xdtype, (bq, bk, bv, bo), cfg, dt, Skv = ctx.meta
+		H, W, n_head, ks, stride, pad = cfg
+		dh = C // n_head
+		dy2 = _flat(cast(dy, dt))
+		dwo, dbo = linear_wgrad(dy2, o), colsum(dy2)
+		do = linear_dgrad(dy2, weight_as(wo, dt))
+		dq, dk1, dv1 = torch.empty_like(q), torch.empty_like(k1), torch.empty_like(v1)
+		attention_bwd(do, q, k1, v1, o, lse, dq, dk1, dv1, Bn, n_head, S, Skv, dh)
+		dk0, dck = dwconv_bwd(dk1, k0, weight_as(ck, dt), Bn, H, W, C, ks, stride, pad)
+		dv0, dcv = dwconv_bwd(dv1, v0, weight_as(cv, dt), Bn, H, W, C, ks, stride, pad)
+		dwq, dbq = linear_wgrad(dq, x2), colsum(dq)
+		dwk, dbk = linear_wgrad(dk0, x2), colsum(dk0)
+		dwv, dbv = linear_wgrad(dv0, x2), colsum(dv0)
+		dx = None
+		if ctx.needs_input_grad[0]:
+			# dx = dq Wq + dk0 Wk + dv0 Wv: the second and third GEMM add onto the first through the residual epilogue (C aliases aux)
+			dx = linear_dgrad(dq, weight_as(wq, dt))
+			for g_, w_ in ((dk0, wk), (dv0, wv)):
+				gemm(g_, weight_as(w_, dt), dx, Bn * S, C, C, C, C, C, b_layout=L.MN_MAJOR, epilogue=L.EPI_RESIDUAL, aux=dx, ld_aux=C)
+			dx = dx.reshape(Bn, S, C)
+			if dx.dtype != xdtype:
+				dx = cast(dx, xdtype)
+		return (dx, grad_as(dwq, wq), grad_as(dbq, bq), grad_as(dwk, wk), grad_as(dbk, bk), grad_as(dwv, wv), grad_as(dbv, bv),
+			grad_as(dck, ck), grad_as(dcv, cv), grad_as(dwo, wo), grad_as(dbo, bo), None)
+
+
+class MeanPoolFn(torch.autograd.Function):
+	"""x.mean(dim=1) over tokens (models/cvt.py:105 of the reference)."""
+
+	@staticmethod
+	def forward(ctx, x):
+		L.require_gpu(x)
+		xc = x.contiguous()
+		Bn, S, d = xc.shape
+		y = torch.empty((Bn, d), dtype=xc.dtype, device=xc.device)
+		L.check(L.load().vitk_mean_pool_fwd(L.ptr(xc), L.ptr(y), Bn, S, d, L.dtype_code(xc.dtype), L.stream()))
+		ctx.meta = (Bn, S, d)
+		return y
+
+	@staticmethod
+	def backward(ctx, dy):
+		Bn, S, d = ctx.meta
+		dyc = dy.contiguous()
+		dx = torch.empty((Bn, S, d), dtype=dyc.dtype, device=dyc.device)
+		L.check(L.load().vitk_mean_pool_bwd(L.ptr(dyc), L.ptr(dx), Bn, S, d, L.dtype_code(dyc.dtype), L.stream()))
+		return dx
