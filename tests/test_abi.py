@@ -111,3 +111,43 @@ def test_feedforward_interface():
 	Cfg.activation = "tanh"
 	with pytest.raises(ValueError):
 		FeedForward(Cfg())
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/models"), reason="reference checkout not present (GPU box)")
+def test_reference_models_construct_on_top_of_these_layers():
+	"""The import switch of INTEGRATION.md: the reference's own models/vit.py and models/cvt.py build, unchanged, on
+	vit_amd.layers (run in a subprocess so that sys.modules of the test process stays clean)."""
+	import subprocess
+	import sys
+	code = r'''
+import sys
+sys.path.insert(0, %r)
+import vit_amd.layers
+import vit_amd.layers.embeddings, vit_amd.layers.attention, vit_amd.layers.norm, vit_amd.layers.transformers
+import vit_amd.layers.vit, vit_amd.layers.cvt, vit_amd.layers.conv
+sys.modules["layers"] = vit_amd.layers
+for m in ("embeddings", "attention", "norm", "transformers", "vit", "cvt", "conv"):
+	sys.modules["layers." + m] = getattr(vit_amd.layers, m)
+sys.path.insert(1, "/root/reference")
+import torch.nn as nn
+from config import ViTConfig, CvTConfig
+from layers.attention import MHA
+from models.vit import ViT
+from models.cvt import CvT
+import vit_amd.models as ours
+class C(ViTConfig):
+	attention = MHA
+	norm = nn.LayerNorm
+	dropout = 0.0
+ref_on_ours = ViT(C())
+assert type(ref_on_ours.blocks[0]).__module__ == "vit_amd.layers.vit"
+assert list(ref_on_ours.state_dict()) == list(ours.ViT(C()).state_dict())
+class CC(CvTConfig):
+	dropout = 0.0
+cv = CvT(CC())
+assert type(cv.stage1_blocks[0].attn).__module__ == "vit_amd.layers.attention"
+assert sorted(cv.state_dict()) == sorted(ours.CvT(CC()).state_dict())
+print("ok")
+''' % ROOT
+	out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+	assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
