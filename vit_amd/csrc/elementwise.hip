@@ -61,25 +61,26 @@ struct DropF {
 };
 
 // ---- column sum: out[n] += sum_m x[m*ld + n] ------------------------------------------------------
+// blockDim = (CX, RY): CX lanes own VEC consecutive columns each, RY row groups stream disjoint rows with 4
+// independent 16-byte loads in flight per lane; the row groups combine through LDS and the block issues ONE float
+// atomic per column, so a column sees only gridDim.y (<= 128) atomics.
 template <typename T, int VEC>
-__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, float* out, int64_t M, int64_t N, int64_t ld) {
-	__shared__ float red[4][64 * VEC];
-	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-	const int64_t col = ((int64_t)blockIdx.x * 64 + lane) * VEC;
+__global__ __launch_bounds__(1024) void colsum_kernel(const T* __restrict__ x, float* out, int64_t M, int64_t N, int64_t ld) {
+	extern __shared__ __attribute__((aligned(16))) float red[];  // [RY][CX * VEC]
+	const int cx = threadIdx.x, ry = threadIdx.y, CX = blockDim.x, RY = blockDim.y;
+	const int64_t col = ((int64_t)blockIdx.x * CX + cx) * VEC;
 	float acc[VEC];
 #pragma unroll
 	for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
 	if (col < N) {
-		// 8 independent row loads in flight per lane; few workgroups per column strip keep the final float atomics
-		// (one per column per workgroup) far below the contended-atomic rate
-		const int64_t stride = (int64_t)gridDim.y * 4;
-		int64_t m = (int64_t)blockIdx.y * 4 + wave;
-		for (; m + 7 * stride < M; m += 8 * stride) {
-			float v[8][VEC];
+		const int64_t stride = (int64_t)gridDim.y * RY;
+		int64_t m = (int64_t)blockIdx.y * RY + ry;
+		for (; m + 3 * stride < M; m += 4 * stride) {
+			float v[4][VEC];
 #pragma unroll
-			for (int u = 0; u < 8; ++u) load_vec<T, VEC>(x + (m + u * stride) * ld + col, v[u]);
+			for (int u = 0; u < 4; ++u) load_vec<T, VEC>(x + (m + u * stride) * ld + col, v[u]);
 #pragma unroll
-			for (int u = 0; u < 8; ++u)
+			for (int u = 0; u < 4; ++u)
 #pragma unroll
 				for (int j = 0; j < VEC; ++j) acc[j] += v[u][j];
 		}
@@ -91,12 +92,13 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, fl
 		}
 	}
 #pragma unroll
-	for (int j = 0; j < VEC; ++j) red[wave][lane * VEC + j] = acc[j];
+	for (int j = 0; j < VEC; ++j) red[(ry * CX + cx) * VEC + j] = acc[j];
 	__syncthreads();
-	if (wave == 0 && col < N) {
+	if (ry == 0 && col < N) {
 #pragma unroll
 		for (int j = 0; j < VEC; ++j) {
-			const float s = red[0][lane * VEC + j] + red[1][lane * VEC + j] + red[2][lane * VEC + j] + red[3][lane * VEC + j];
+			float s = 0.f;
+			for (int r = 0; r < RY; ++r) s += red[(r * CX + cx) * VEC + j];
 			atomicAdd(&out[col + j], s);
 		}
 	}
@@ -106,12 +108,17 @@ template <typename T>
 int launch_colsum(const void* x, float* out, int64_t M, int64_t N, int64_t ld, hipStream_t st) {
 	constexpr int V = VecOf<T>::N;
 	const bool vec = (N % V == 0) && (ld % V == 0) && vitk_aligned(x, 16);
-	const int64_t strips = vitk_cdiv(N, 64 * (vec ? V : 1));
-	int64_t slabs = std::min<int64_t>(vitk_cdiv(M, 32), std::max<int64_t>(1, 1024 / strips));
+	const int vw = vec ? V : 1;
+	const int64_t chunks = vitk_cdiv(N, vw);
+	const int cx = (int)std::min<int64_t>(128, vitk_cdiv(chunks, 32) * 32);  // lanes along columns
+	const int ry = std::max(1, 1024 / cx);
+	const unsigned gx = (unsigned)vitk_cdiv(chunks, cx);
+	const unsigned gy = (unsigned)std::max<int64_t>(1, std::min<int64_t>(vitk_cdiv(M, (int64_t)ry * 4), 128));
+	const size_t lds = (size_t)ry * cx * vw * sizeof(float);
 	if (vec)
-		hipLaunchKernelGGL((colsum_kernel<T, V>), dim3((unsigned)strips, (unsigned)slabs), dim3(256), 0, st, (const T*)x, out, M, N, ld);
+		hipLaunchKernelGGL((colsum_kernel<T, V>), dim3(gx, gy), dim3(cx, ry), lds, st, (const T*)x, out, M, N, ld);
 	else
-		hipLaunchKernelGGL((colsum_kernel<T, 1>), dim3((unsigned)strips, (unsigned)slabs), dim3(256), 0, st, (const T*)x, out, M, N, ld);
+		hipLaunchKernelGGL((colsum_kernel<T, 1>), dim3(gx, gy), dim3(cx, ry), lds, st, (const T*)x, out, M, N, ld);
 	VITK_CHECK_LAUNCH();
 	return VITK_OK;
 }

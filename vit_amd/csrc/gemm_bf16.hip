@@ -286,9 +286,10 @@ bool vitk_gemm_bf16_ok(const vitk_gemm_desc& d) {
 
 int vitk_gemm_bf16(const vitk_gemm_desc& d, hipStream_t st) {
 	static const bool big_tiles = getenv("VITK_NO_BIG_TILE") == nullptr;  // debugging / A-B switch
-	static const bool v3 = getenv("VITK_GEMM_V3") != nullptr;
-	if (big_tiles && v3 && vitk_gemm_bf16_v3_ok(d)) return vitk_gemm_bf16_v3(d, st);
-	if (big_tiles && vitk_gemm_bf16_256_ok(d)) return vitk_gemm_bf16_256(d, st);
+	if (big_tiles && vitk_gemm_bf16_256_ok(d)) {
+		const int rc = vitk_gemm_bf16_256(d, st);
+		if (rc != VITK_ERR_UNSUPPORTED) return rc;
+	}
 	BfArgs a{};
 	a.g = make_gemm_dev(d);
 	a.tiles_m = (int)vitk_cdiv(d.M, BM);

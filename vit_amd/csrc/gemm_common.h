@@ -132,5 +132,3 @@ int vitk_gemm_bf16(const vitk_gemm_desc& d, hipStream_t st);  // returns VITK_ER
 bool vitk_gemm_bf16_ok(const vitk_gemm_desc& d);
 bool vitk_gemm_bf16_256_ok(const vitk_gemm_desc& d);  // large-tile LDS-DMA kernel (needs K % 64 == 0, M, N >= 256)
 int vitk_gemm_bf16_256(const vitk_gemm_desc& d, hipStream_t st);
-bool vitk_gemm_bf16_v3_ok(const vitk_gemm_desc& d);   // pipelined 256x256x32 ring kernel
-int vitk_gemm_bf16_v3(const vitk_gemm_desc& d, hipStream_t st);

@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256) void norm_bwd_kernel(const T* __restrict__ dy,
 	for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += nwaves) {
 		const float mu = RMS ? 0.f : mean[row];
 		const float rs = rstd_in[row];
-		float xh[ITERS][VEC], g[ITERS][VEC];
+		float xh[ITERS][VEC], g[ITERS][VEC], rres[ITERS][VEC];
 		float s1 = 0.f, s2 = 0.f;
 #pragma unroll
 		for (int it = 0; it < ITERS; ++it) {
@@ -128,6 +128,7 @@ __global__ __launch_bounds__(256) void norm_bwd_kernel(const T* __restrict__ dy,
 				float dyv[VEC];
 				load_vec<T, VEC>(x + row * d + c * VEC, xh[it]);
 				load_vec<T, VEC>(dy + row * d + c * VEC, dyv);
+				if (dres != nullptr) load_vec<T, VEC>(dres + row * d + c * VEC, rres[it]);  // issued with the other loads
 #pragma unroll
 				for (int j = 0; j < VEC; ++j) {
 					xh[it][j] = (xh[it][j] - mu) * rs;
@@ -155,10 +156,8 @@ __global__ __launch_bounds__(256) void norm_bwd_kernel(const T* __restrict__ dy,
 #pragma unroll
 				for (int j = 0; j < VEC; ++j) o[j] = (g[it][j] - s1 - xh[it][j] * s2) * rs;
 				if (dres != nullptr) {
-					float r[VEC];
-					load_vec<T, VEC>(dres + row * d + c * VEC, r);
 #pragma unroll
-					for (int j = 0; j < VEC; ++j) o[j] += r[j];
+					for (int j = 0; j < VEC; ++j) o[j] += rres[it][j];
 				}
 				store_vec<T, VEC>(dx + row * d + c * VEC, o);
 			}
@@ -203,7 +202,7 @@ int launch_fwd(const NormArgs& a, hipStream_t st) {
 }
 template <typename T, int VEC, int ITERS, bool RMS>
 int launch_bwd(const NormArgs& a, hipStream_t st) {
-	int grid = (int)std::min<int64_t>(vitk_cdiv(a.rows, 4), 1024);
+	int grid = (int)std::min<int64_t>(vitk_cdiv(a.rows, 4), 2048);
 	size_t lds = (size_t)2 * a.d * sizeof(float);
 	hipLaunchKernelGGL((norm_bwd_kernel<T, VEC, ITERS, RMS>), dim3(grid), dim3(256), lds, st, (const T*)a.dy, (const T*)a.x, a.gamma, a.mean_in,
 		a.rstd_in, (const T*)a.dres, (T*)a.dx, a.dgamma, a.dbeta, a.rows, a.d, a.offset);
