@@ -100,6 +100,42 @@ def test_gemm_epilogues(gpu, dtype, act):
 	assert relerr(du, (dyr @ w2r) * O.act_grad(pre.cpu().double(), act)) < TOL[dtype]
 
 
+@pytest.mark.parametrize("act", ["gelu", "silu"])
+def test_gemm_more_tiles_than_cus(gpu, act):
+	"""bf16 GEMMs with more 256x256 output tiles than the GPU has CUs (ragged last tile row and column): the
+	persistent kernel walks several tiles per workgroup and writes the epilogue straight from the accumulators."""
+	from vit_amd import ops
+	import vit_amd._lib as L
+	dtype = torch.bfloat16
+	M, N, K = 4363, 3848, 128
+	x, xr = rnd((M, K), dtype, gpu, seed=1)
+	w, wr = rnd((N, K), dtype, gpu, 0.1, seed=2)
+	bias = torch.randn(N, generator=torch.Generator().manual_seed(3))
+	code = L.ACT_CODES[act]
+	plain = ops.linear_fwd(x, w, None)
+	assert relerr(plain, xr @ wr.t()) < TOL[dtype]
+	y, pre = ops.linear_fwd(x, w, bias.to(gpu), act=code, save_pre=True)
+	pre_ref = xr @ wr.t() + bias.double()
+	assert relerr(pre, pre_ref) < TOL[dtype]
+	assert relerr(y, O.act_fwd(pre.cpu().double(), act)) < TOL[dtype]
+	res, rr = rnd((M, N), dtype, gpu, seed=4)
+	gamma = torch.rand(N, generator=torch.Generator().manual_seed(5)) + 0.5
+	y2 = ops.linear_fwd(x, w, bias.to(gpu), residual=res, gamma=gamma.to(gpu))
+	assert relerr(y2, rr + gamma.double() * pre_ref) < TOL[dtype]
+	dy, dyr = rnd((M, K), dtype, gpu, seed=6)
+	w2, w2r = rnd((K, N), dtype, gpu, 0.1, seed=7)
+	dx = ops.linear_dgrad(dy, w2)
+	assert relerr(dx, dyr @ w2r) < TOL[dtype]
+	du = ops.linear_dgrad(dy, w2, act=code, pre=pre)
+	assert relerr(du, (dyr @ w2r) * O.act_grad(pre.cpu().double(), act)) < TOL[dtype]
+	# exact small integers through the same path: any tile-walk or fragment-placement error is a wrong integer
+	g = torch.Generator().manual_seed(8)
+	a = torch.randint(-3, 4, (M, K), generator=g).to(dtype)
+	b = torch.randint(-3, 4, (N, K), generator=g).to(dtype)
+	c = ops.linear_fwd(a.to(gpu), b.to(gpu), None)
+	assert torch.equal(c.cpu().double(), (a.double() @ b.double().t()).to(dtype).double())
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("kind", ["layernorm", "rmsnorm"])
 @pytest.mark.parametrize("rows,d", [(37, 768), (9, 192), (5, 40), (3, 50), (11, 2048)])

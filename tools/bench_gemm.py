@@ -10,17 +10,21 @@ M = 256 * 197
 shapes = [("qkv", M, 2304, 768), ("proj", M, 768, 768), ("fc_in", M, 3072, 768), ("fc_out", M, 768, 3072)]
 
 
-def timeit(fn, iters=10):
+def timeit(fn, iters=20, reps=3):
+	"""best of `reps` averages over `iters` launches"""
 	for _ in range(3):
 		fn()
-	torch.cuda.synchronize()
-	e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-	e0.record()
-	for _ in range(iters):
-		fn()
-	e1.record()
-	torch.cuda.synchronize()
-	return e0.elapsed_time(e1) / iters * 1e-3
+	best = 1e9
+	for _ in range(reps):
+		torch.cuda.synchronize()
+		e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+		e0.record()
+		for _ in range(iters):
+			fn()
+		e1.record()
+		torch.cuda.synchronize()
+		best = min(best, e0.elapsed_time(e1) / iters * 1e-3)
+	return best
 
 
 for name, m, n, k in shapes:

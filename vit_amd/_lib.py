@@ -10,7 +10,7 @@ from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_void_p
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvitk.so")
+LIB_PATH = os.environ.get("VITK_LIB") or os.path.join(_HERE, "libvitk.so")  # VITK_LIB: explicit path of another build (A/B runs)
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_GELU, ACT_SILU, ACT_RELU, ACT_RELU6 = 0, 1, 2, 3, 4

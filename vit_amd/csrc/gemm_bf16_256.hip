@@ -53,26 +53,35 @@ __device__ __forceinline__ bf16x8 read_frag(const char* tile, int base, int s, i
 	}
 }
 
-// LDS-DMA of one 256 x 64 operand tile: 32 pieces of 1 KiB, 4 per wave.
+// LDS-DMA of one 256 x 64 operand tile: 32 pieces of 1 KiB, 4 per wave.  Every source address is a wave-uniform
+// 64-bit base (scalar registers) plus a 32-bit per-lane byte offset that is recomputed from the lane id on each call
+// (the empty asm keeps the compiler from hoisting 16 loop-invariant address registers into the MFMA loop, where the
+// accumulators leave no room for them).
 template <int LAYOUT>
 __device__ __forceinline__ void stage_tile(char* tile, const bf16_t* __restrict__ base, int64_t ld, int64_t mn0, int64_t mn_total, int k0, int wave, int lane) {
+	asm volatile("" : "+v"(lane));
+	const int ldi = (int)ld;
 #pragma unroll
 	for (int j = 0; j < 4; ++j) {
 		const int piece = 4 * wave + j;
-		const bf16_t* src;
+		const char* src;
 		if (LAYOUT == VITK_K_MAJOR) {
 			const int r = lane >> 3;  // == row & 7
-			int64_t row = mn0 + 8 * piece + r;
-			if (row >= mn_total) row = mn_total - 1;
 			const int chunk = (lane & 7) ^ r;
-			src = base + row * ld + k0 + 8 * chunk;
+			int64_t rowbase = mn0 + 8 * piece;  // rows past the end re-read the last row (their products are never stored)
+			if (rowbase > mn_total - 1) rowbase = mn_total - 1;
+			const int rlim = (int)(mn_total - 1 - rowbase);
+			const int rr = r < rlim ? r : rlim;
+			const uint32_t voff = (uint32_t)(rr * ldi + 8 * chunk) * 2u;
+			src = reinterpret_cast<const char*>(base + rowbase * ld + k0) + voff;
 		} else {
-			const int krow = 2 * piece + (lane >> 5);
-			const int pc = lane & 31;
-			const int chunk = ((((pc >> 1) ^ fk(krow)) << 1) | (pc & 1));
-			int64_t col = mn0 + 8 * chunk;
-			if (col > mn_total - 8) col = mn_total - 8;
-			src = base + (int64_t)(k0 + krow) * ld + col;
+			const int hi = lane >> 5, pc = lane & 31;
+			const int krow_u = 2 * piece;
+			const int chunk = ((((pc >> 1) ^ fk(krow_u + hi)) << 1) | (pc & 1));
+			const int clim = (int)(mn_total - 8 - mn0);  // >= 0: MN-major extents are multiples of 8
+			const int coff = 8 * chunk < clim ? 8 * chunk : clim;
+			const uint32_t voff = (uint32_t)(hi * ldi + coff) * 2u;
+			src = reinterpret_cast<const char*>(base + (int64_t)(k0 + krow_u) * ld + mn0) + voff;
 		}
 		__builtin_amdgcn_global_load_lds((gbl_void_p)src, (lds_void_p)(tile + piece * 1024), 16, 0, 0);
 	}
@@ -88,11 +97,72 @@ __device__ __forceinline__ void static_for(F&& f) {
 	}
 }
 
+// One K step (64) of the 256x256 tile for one wave: 2 x (4 B fragments, 8 A fragments, 32 MFMAs).  The fragment reads
+// are software-pipelined two A fragments ahead of the MFMAs that use them, and sched_group_barrier pins that order
+// (left alone, the compiler issues each read right before its first use and the MFMA pipe idles for the LDS latency).
+// Measured on the ViT-B/16 shapes: +5..15 % with a K-major A operand; with an MN-major A operand (two transposing
+// reads per fragment, weight-gradient GEMMs) the compiler's own order is 3 % faster and is kept.
+template <int ALAYOUT, int BLAYOUT>
+__device__ __forceinline__ void mma_stage(const char* sa, const char* sb, f32x4 (&acc)[8][4], int wm, int wn, int lane) {
+	if constexpr (ALAYOUT == VITK_K_MAJOR) {
+		constexpr int RB = BLAYOUT == VITK_K_MAJOR ? 1 : 2;  // LDS reads per B fragment
+		bf16x8 wf[2][4], xf[3];
+#pragma unroll
+		for (int j = 0; j < 4; ++j) wf[0][j] = read_frag<BLAYOUT>(sb, wn + 16 * j, 0, lane);
+		xf[0] = read_frag<ALAYOUT>(sa, wm, 0, lane);
+		xf[1] = read_frag<ALAYOUT>(sa, wm + 16, 0, lane);
+		static_for<0, 16>([&](auto gc) {
+			constexpr int g = decltype(gc)::value, s = g >> 3, i = g & 7;
+			if constexpr (g + 2 < 16) xf[(g + 2) % 3] = read_frag<ALAYOUT>(sa, wm + 16 * ((g + 2) & 7), (g + 2) >> 3, lane);
+			if constexpr (g == 4) {
+#pragma unroll
+				for (int j = 0; j < 4; ++j) wf[1][j] = read_frag<BLAYOUT>(sb, wn + 16 * j, 1, lane);
+			}
+#pragma unroll
+			for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[s][j], xf[g % 3], acc[i][j], 0, 0, 0);
+		});
+		// the order above, spelled out for the instruction scheduler: 0x100 = LDS reads, 0x008 = MFMAs
+		__builtin_amdgcn_sched_group_barrier(0x100, 4 * RB + 2, 0);
+		static_for<0, 16>([&](auto gc) {
+			constexpr int g = decltype(gc)::value;
+			constexpr int reads = (g + 2 < 16 ? 1 : 0) + (g == 4 ? 4 * RB : 0);
+			if constexpr (reads > 0) __builtin_amdgcn_sched_group_barrier(0x100, reads, 0);
+			__builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+		});
+	} else {
+#pragma unroll
+		for (int s = 0; s < 2; ++s) {
+			bf16x8 xf[8], wf[4];
+#pragma unroll
+			for (int j = 0; j < 4; ++j) wf[j] = read_frag<BLAYOUT>(sb, wn + 16 * j, s, lane);
+#pragma unroll
+			for (int i = 0; i < 8; ++i) xf[i] = read_frag<ALAYOUT>(sa, wm + 16 * i, s, lane);
+#pragma unroll
+			for (int i = 0; i < 8; ++i)
+#pragma unroll
+				for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], acc[i][j], 0, 0, 0);
+		}
+	}
+}
+
 struct BigArgs {
 	GemmDev g;
 	int tiles_m, tiles_n, splits, k_per_split;
 	int vec4, vec8;  // epilogue operands / outputs may be accessed 4-wide (8 / 16 bytes) resp. 8-wide (16 bytes bf16)
+#ifdef VITK_GEMM_STAMPS
+	long long* stamps;  // diagnostic builds only: [workgroup][round][8] timestamps of the persistent kernel
+	int stagger;        // diagnostic builds only: start delay step in 10 ns ticks
+#endif
 };
+
+#ifdef VITK_GEMM_STAMPS
+long long* g_stamps = nullptr;
+int g_stagger = 0;
+#define STAMP(slot) \
+	if (a.stamps != nullptr && tid == 0 && round < 16) a.stamps[((int64_t)blockIdx.x * 16 + round) * 8 + (slot)] = wall_clock64()
+#else
+#define STAMP(slot)
+#endif
 
 template <typename TOUT>
 __device__ __forceinline__ void store4(const BigArgs& a, int64_t m, int64_t nb, f32x4 v) {
@@ -129,7 +199,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_256_kernel(BigArgs a) {
 	const int gsz = min(a.tiles_m - first_m, GM);
 	const int tm = first_m + (wg % per_group) % gsz;
 	const int tn = (wg % per_group) / gsz;
-	const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
+	int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
 
 	const int k_begin = blockIdx.y * a.k_per_split;
 	const int k_end = min((int)g.K, k_begin + a.k_per_split);
@@ -144,9 +214,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_256_kernel(BigArgs a) {
 #pragma unroll
 		for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+#ifdef VITK_GEMM_STAMPS
+	const int round = 0;
+#endif
+	STAMP(0);
 	stage_tile<ALAYOUT>(smem, A, g.lda, m0, g.M, k_begin, wave, lane);
 	stage_tile<BLAYOUT>(smem + TILE_BYTES, B, g.ldb, n0, g.N, k_begin, wave, lane);
 	__syncthreads();  // with LDS-DMA in flight hipcc drains vmcnt(0) ahead of the barrier
+	STAMP(1);
 
 	for (int t = 0; t < nt; ++t) {
 		const char* sa = smem + (t & 1) * STAGE_BYTES;
@@ -157,21 +232,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_256_kernel(BigArgs a) {
 			stage_tile<ALAYOUT>(da, A, g.lda, m0, g.M, k0, wave, lane);
 			stage_tile<BLAYOUT>(da + TILE_BYTES, B, g.ldb, n0, g.N, k0, wave, lane);
 		}
-#pragma unroll
-		for (int s = 0; s < 2; ++s) {
-			bf16x8 xf[8], wf[4];
-#pragma unroll
-			for (int j = 0; j < 4; ++j) wf[j] = read_frag<BLAYOUT>(sb, wn + 16 * j, s, lane);
-#pragma unroll
-			for (int i = 0; i < 8; ++i) xf[i] = read_frag<ALAYOUT>(sa, wm + 16 * i, s, lane);
-#pragma unroll
-			for (int i = 0; i < 8; ++i)
-#pragma unroll
-				for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], acc[i][j], 0, 0, 0);
-		}
+		mma_stage<ALAYOUT, BLAYOUT>(sa, sb, acc, wm, wn, lane);
 		__syncthreads();  // next stage landed (vmcnt(0) drained by the fence) and everyone is done with this one
 	}
 
+	STAMP(2);
+#ifdef VITK_GEMM_STAMPS
+	if (a.stagger == -1) m0 = n0 = 0;
+#endif
 	if constexpr (std::is_same<TOUT, bf16_t>::value) {
 		// bf16 output: the fused epilogue runs in the accumulator layout (each lane owns 4 consecutive columns of one
 		// row: float4 bias, 8-byte residual / pre-activation operand), the result is rounded to bf16 and the whole
@@ -246,6 +314,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_256_kernel(BigArgs a) {
 			});
 		});
 		__syncthreads();
+		STAMP(3);
 		bf16_t* outp = reinterpret_cast<bf16_t*>(g.C);
 		for (int it = 0; it < (BM * BN / 8) / NTHREADS; ++it) {
 			const int v = it * NTHREADS + tid;
@@ -262,6 +331,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_256_kernel(BigArgs a) {
 					if (nb + r < g.N) outp[m * g.ldc + nb + r] = e[r];
 			}
 		}
+		STAMP(4);
 	} else {
 		// float32 output (weight gradients, split-K partial sums): through a float LDS image, 128 rows at a time
 		float* ct = reinterpret_cast<float*>(smem);
@@ -298,6 +368,239 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_256_kernel(BigArgs a) {
 	}
 }
 
+// Epilogue of one wave's 128x64 accumulator tile through a wave-PRIVATE float LDS image, 32 rows at a time, with no
+// workgroup barrier: the wave writes 8 fragments (accumulator layout: 16 rows x 16 bytes per wave-instruction), reads
+// them back as rows (each lane 8 consecutive columns) and does the fused math there, so that the epilogue operands
+// arrive and the results leave in 16-byte accesses, 8 rows x 128 contiguous bytes per wave-instruction.  (In the
+// accumulator layout itself a wave-instruction touches 16 rows x 32 bytes, and the CU's memory pipeline takes about as
+// long per instruction for those 512 bytes as for 1 KiB in whole lines.)
+constexpr int EW_LD = 68;                    // floats per image row: 64 + 4 pad (conflict-free for both access shapes)
+constexpr int EW_BYTES = 32 * EW_LD * 4;     // 8,704 B per wave
+constexpr int LDSP_BYTES = STAGE_BYTES + 8 * EW_BYTES;  // stage 0 stays free for the next tile's first K step
+
+// Per-tile epilogue operands a lane keeps in registers: bias / LayerScale of its 8 columns and the first 32 rows of the
+// residual / pre-activation operand.  Loaded BEFORE the next tile's LDS-DMA is issued: the memory counter retires in
+// order, so anything requested after the DMA could only be consumed once the DMA has landed.
+struct EpiRegs {
+	float bias8[8], gamma8[8];
+	bf16x8 aux0[4];
+};
+
+template <int EPI>
+__device__ __forceinline__ void epilogue_prefetch(const BigArgs& a, EpiRegs& er, bool full, int64_t m0w, int64_t n0w, int lane) {
+	const GemmDev& g = a.g;
+	const int c8 = lane & 7, r8 = lane >> 3;
+	const int64_t nb = n0w + 8 * c8;
+#pragma unroll
+	for (int e = 0; e < 8; ++e) {
+		er.bias8[e] = 0.f;
+		er.gamma8[e] = 1.f;
+	}
+	if (!full) return;
+	if (g.bias != nullptr) {
+		load_vec<float, 4>(g.bias + nb, *reinterpret_cast<float(*)[4]>(&er.bias8[0]));
+		load_vec<float, 4>(g.bias + nb + 4, *reinterpret_cast<float(*)[4]>(&er.bias8[4]));
+	}
+	if (EPI == VITK_EPI_RESIDUAL && g.gamma != nullptr) {
+		load_vec<float, 4>(g.gamma + nb, *reinterpret_cast<float(*)[4]>(&er.gamma8[0]));
+		load_vec<float, 4>(g.gamma + nb + 4, *reinterpret_cast<float(*)[4]>(&er.gamma8[4]));
+	}
+	if (EPI == VITK_EPI_RESIDUAL || EPI == VITK_EPI_ACTGRAD) {
+		const bf16_t* aux = reinterpret_cast<const bf16_t*>(g.aux);
+#pragma unroll
+		for (int it = 0; it < 4; ++it) {
+			const int64_t m = m0w + 8 * it + r8;
+			er.aux0[it] = *reinterpret_cast<const bf16x8*>(aux + m * g.ld_aux + nb);
+		}
+	}
+}
+
+// `full`: wave-uniform, the wave's 128 rows x 64 columns are all inside M x N and every operand may be accessed 16
+// bytes wide; then the whole epilogue is straight-line code.
+template <int EPI, int ACT>
+__device__ __forceinline__ void epilogue_wave_private(const BigArgs& a, const f32x4 (&acc)[8][4], const EpiRegs& er, bool full, float* img, int64_t m0w, int64_t n0w, int lane) {
+	const GemmDev& g = a.g;
+	const int c8 = lane & 7, r8 = lane >> 3;
+	const int64_t nb = n0w + 8 * c8;
+	const bf16_t* aux = reinterpret_cast<const bf16_t*>(g.aux);
+	bf16_t* out2 = reinterpret_cast<bf16_t*>(g.out2);
+	bf16_t* outp = reinterpret_cast<bf16_t*>(g.C);
+	constexpr bool HAS_AUX = EPI == VITK_EPI_RESIDUAL || EPI == VITK_EPI_ACTGRAD;
+	auto write_quarter = [&](auto qc) {
+		constexpr int qq = decltype(qc)::value;
+#pragma unroll
+		for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+			for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(img + (16 * ii + (lane & 15)) * EW_LD + 16 * j + 4 * (lane >> 4)) = acc[2 * qq + ii][j];
+	};
+	// The same wave reads what it wrote: LDS operations of one wave complete in order, so no barrier anywhere.
+	if (!full) {
+		// ragged edge tile or unaligned operands: one element at a time through the generic epilogue
+		static_for<0, 4>([&](auto qc) {
+			constexpr int qq = decltype(qc)::value;
+			write_quarter(qc);
+#pragma unroll 1
+			for (int idx = lane; idx < 32 * 64; idx += 64) {
+				const int row = idx >> 6, col = idx & 63;
+				const int64_t m = m0w + 32 * qq + row, n = n0w + col;
+				if (m < g.M && n < g.N) epi_store1<bf16_t, bf16_t, EPI, ACT>(g, m, n, img[row * EW_LD + col]);
+			}
+		});
+		return;
+	}
+	bf16x8 auxv[2][4];
+	if (HAS_AUX) {
+#pragma unroll
+		for (int it = 0; it < 4; ++it) auxv[0][it] = er.aux0[it];
+	}
+	static_for<0, 4>([&](auto qc) {
+		constexpr int qq = decltype(qc)::value;
+		// operand rows of the NEXT quarter: requested one LDS round trip ahead of their use
+		if (HAS_AUX && qq < 3) {
+#pragma unroll
+			for (int it = 0; it < 4; ++it) {
+				const int64_t m = m0w + 32 * (qq + 1) + 8 * it + r8;
+				auxv[(qq + 1) & 1][it] = *reinterpret_cast<const bf16x8*>(aux + m * g.ld_aux + nb);
+			}
+		}
+		write_quarter(qc);
+#pragma unroll
+		for (int it = 0; it < 4; ++it) {
+			const int row = 8 * it + r8;
+			const int64_t m = m0w + 32 * qq + row;
+			const f32x4 lo = *reinterpret_cast<const f32x4*>(img + row * EW_LD + 8 * c8);
+			const f32x4 hi = *reinterpret_cast<const f32x4*>(img + row * EW_LD + 8 * c8 + 4);
+			float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#pragma unroll
+			for (int e = 0; e < 8; ++e) v[e] += er.bias8[e];
+			if (EPI == VITK_EPI_ACT) {
+				if (out2 != nullptr) {
+					bf16x8 pre;
+#pragma unroll
+					for (int e = 0; e < 8; ++e) {
+						pre[e] = (bf16_t)v[e];
+						v[e] = (float)pre[e];  // the activation sees the pre-activation as stored
+					}
+					*reinterpret_cast<bf16x8*>(out2 + m * g.ld_out2 + nb) = pre;
+				}
+#pragma unroll
+				for (int e = 0; e < 8; ++e) v[e] = act_apply(v[e], ACT >= 0 ? ACT : g.act);
+			} else if (EPI == VITK_EPI_RESIDUAL) {
+#pragma unroll
+				for (int e = 0; e < 8; ++e) v[e] = (float)auxv[qq & 1][it][e] + er.gamma8[e] * v[e];
+			} else if (EPI == VITK_EPI_ACTGRAD) {
+#pragma unroll
+				for (int e = 0; e < 8; ++e) v[e] *= act_deriv((float)auxv[qq & 1][it][e], ACT >= 0 ? ACT : g.act);
+			}
+			bf16x8 pk;
+#pragma unroll
+			for (int e = 0; e < 8; ++e) pk[e] = (bf16_t)v[e];
+			*reinterpret_cast<bf16x8*>(outp + m * g.ldc + nb) = pk;
+		}
+	});
+}
+
+// Persistent form for bf16 outputs with more tiles than CUs: one workgroup per CU walks the tile list; after the last
+// K step of a tile it first issues the LDS-DMA of the NEXT tile's first K step (into stage 0) and only then runs the
+// epilogue (through stage 1 and the spare LDS), so output stores, epilogue operand loads and the next tile's operand
+// fetch overlap and no workgroup is launched or drained between tiles.
+template <int ALAYOUT, int BLAYOUT, int EPI, int ACT>
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_256p_kernel(BigArgs a) {
+	extern __shared__ __attribute__((aligned(16))) char smem[];
+	const GemmDev& g = a.g;
+	const int tid = threadIdx.x, lane = tid & 63;
+	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+	const int wm = (wave >> 2) * 128, wn = (wave & 3) * 64;
+	const int ntiles = a.tiles_m * a.tiles_n;
+	const int nblk = gridDim.x;  // a multiple of 8
+	const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+	constexpr int GM = 4;
+	const int per_group = GM * a.tiles_n;
+
+	// tile of this workgroup in a round: consecutive tiles (in grouped order) go to workgroups that share an XCD
+	auto tile_of = [&](int round, int64_t& m0, int64_t& n0) -> bool {
+		const int base = round * nblk;
+		const int n = min(nblk, ntiles - base);
+		if (n <= 0) return false;
+		const int q = n >> 3, r = n & 7;
+		if (idx >= q + (xcd < r ? 1 : 0)) return false;
+		const int wg = base + (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+		const int group = wg / per_group;
+		const int first_m = group * GM;
+		const int gsz = min(a.tiles_m - first_m, GM);
+		const int tm = first_m + (wg % per_group) % gsz;
+		const int tn = (wg % per_group) / gsz;
+		m0 = (int64_t)tm * BM;
+		n0 = (int64_t)tn * BN;
+		return true;
+	};
+
+	const int nt = (int)(g.K / BK);
+	const bf16_t* A = reinterpret_cast<const bf16_t*>(g.A);
+	const bf16_t* B = reinterpret_cast<const bf16_t*>(g.B);
+
+	// LDS: [stage buffer 0: 64 KiB][4 KiB][stage buffer 1: 64 KiB].  The K steps of consecutive tiles form ONE pipeline:
+	// during the last K step of a tile the first K step of the next tile is already being fetched into the other
+	// buffer; the epilogue image takes the buffer that step just vacated plus the 4 KiB in the middle.
+	constexpr int BUF1 = STAGE_BYTES + (8 * EW_BYTES - STAGE_BYTES);
+	int64_t m0 = 0, n0 = 0;
+	bool have = tile_of(0, m0, n0);
+#ifdef VITK_GEMM_STAMPS
+	if (a.stagger > 0) {
+		const long long until = wall_clock64() + (long long)(idx & 3) * a.stagger;
+		while (wall_clock64() < until) __builtin_amdgcn_s_sleep(8);
+	}
+#endif
+	int par = 0;  // buffer of the current K step
+	if (have) {
+		stage_tile<ALAYOUT>(smem, A, g.lda, m0, g.M, 0, wave, lane);
+		stage_tile<BLAYOUT>(smem + TILE_BYTES, B, g.ldb, n0, g.N, 0, wave, lane);
+	}
+	for (int round = 0; have; ++round) {
+		STAMP(0);
+		f32x4 acc[8][4];
+#pragma unroll
+		for (int i = 0; i < 8; ++i)
+#pragma unroll
+			for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+		int64_t nm0 = m0, nn0 = n0;  // after the last tile: re-fetch this tile's first K step (nobody reads it)
+		bool nxt = false;
+		for (int t = 0; t < nt; ++t) {
+			// this step's operands have landed (the barrier's fence drains the DMA) and every wave is done with the
+			// other buffer: the previous K step, or the previous tile's epilogue image
+			__syncthreads();
+			const char* sa = smem + (par ? BUF1 : 0);
+			const char* sb = sa + TILE_BYTES;
+			char* da = smem + (par ? 0 : BUF1);
+			if (t + 1 < nt) {
+				const int k0 = (t + 1) * BK;
+				stage_tile<ALAYOUT>(da, A, g.lda, m0, g.M, k0, wave, lane);
+				stage_tile<BLAYOUT>(da + TILE_BYTES, B, g.ldb, n0, g.N, k0, wave, lane);
+			} else {
+				nxt = tile_of(round + 1, nm0, nn0);
+				stage_tile<ALAYOUT>(da, A, g.lda, nm0, g.M, 0, wave, lane);
+				stage_tile<BLAYOUT>(da + TILE_BYTES, B, g.ldb, nn0, g.N, 0, wave, lane);
+			}
+			mma_stage<ALAYOUT, BLAYOUT>(sa, sb, acc, wm, wn, lane);
+			par ^= 1;
+		}
+		STAMP(2);
+		// now `par` names the buffer the next tile's first K step is landing in; the other one was read last
+		const bool full = a.vec8 && n0 + wn + 64 <= g.N && m0 + wm + 128 <= g.M;
+		EpiRegs er;
+		epilogue_prefetch<EPI>(a, er, full, m0 + wm, n0 + wn, lane);
+		__syncthreads();  // every wave is done with the last K step's buffer (and the requests above have arrived)
+		STAMP(3);
+		float* img = reinterpret_cast<float*>(smem + (par ? 0 : STAGE_BYTES) + wave * EW_BYTES);
+		epilogue_wave_private<EPI, ACT>(a, acc, er, full, img, m0 + wm, n0 + wn, lane);
+		STAMP(4);
+		m0 = nm0;
+		n0 = nn0;
+		have = nxt;
+	}
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the last (unused) DMA must not outlive the workgroup's LDS
+}
+
 template <int AL, int BL, typename TOUT, int EPI, int ACT>
 int launch1(const BigArgs& a, dim3 grid, hipStream_t st) {
 	static bool attr = false;
@@ -309,6 +612,37 @@ int launch1(const BigArgs& a, dim3 grid, hipStream_t st) {
 	hipLaunchKernelGGL((gemm_bf16_256_kernel<AL, BL, TOUT, EPI, ACT>), grid, dim3(NTHREADS), LDS_BYTES, st, a);
 	VITK_CHECK_LAUNCH();
 	return VITK_OK;
+}
+
+int persistent_blocks() {
+	static int n = 0;
+	if (n == 0) {
+		int dev = 0, cus = 0;
+		if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 8) cus = 256;
+		n = cus & ~7;
+	}
+	return n;
+}
+
+template <int AL, int BL, int EPI, int ACT>
+int launchp(const BigArgs& a, hipStream_t st) {
+	static bool attr = false;
+	if (!attr) {
+		hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_256p_kernel<AL, BL, EPI, ACT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSP_BYTES);
+		if (e != hipSuccess) return VITK_ERR_HIP - (int)e;
+		attr = true;
+	}
+	hipLaunchKernelGGL((gemm_bf16_256p_kernel<AL, BL, EPI, ACT>), dim3((unsigned)persistent_blocks()), dim3(NTHREADS), LDSP_BYTES, st, a);
+	VITK_CHECK_LAUNCH();
+	return VITK_OK;
+}
+
+// bf16 outputs: persistent kernel when there is more than one tile per CU, else one workgroup per tile
+template <int AL, int BL, int EPI, int ACT>
+int launch_bf16(const BigArgs& a, dim3 grid, hipStream_t st) {
+	static const bool no_persist = std::getenv("VITK_NO_PERSISTENT") != nullptr;
+	if (!no_persist && a.splits == 1 && (int64_t)a.tiles_m * a.tiles_n > persistent_blocks()) return launchp<AL, BL, EPI, ACT>(a, st);
+	return launch1<AL, BL, bf16_t, EPI, ACT>(a, grid, st);
 }
 
 // Variants instantiated (what the ViT / CvT training step uses); any other combination returns VITK_ERR_UNSUPPORTED
@@ -328,19 +662,19 @@ int launch_variant(const BigArgs& a, const vitk_gemm_desc& d, dim3 grid, hipStre
 	if (d.accumulate) return VITK_ERR_UNSUPPORTED;
 	if (d.a_layout == K && d.b_layout == K) {
 		switch (d.epilogue) {
-			case VITK_EPI_NONE: return launch1<K, K, bf16_t, VITK_EPI_NONE, -1>(a, grid, st);
+			case VITK_EPI_NONE: return launch_bf16<K, K, VITK_EPI_NONE, -1>(a, grid, st);
 			case VITK_EPI_ACT:
-				return d.act == VITK_ACT_GELU ? launch1<K, K, bf16_t, VITK_EPI_ACT, VITK_ACT_GELU>(a, grid, st) : launch1<K, K, bf16_t, VITK_EPI_ACT, -1>(a, grid, st);
-			case VITK_EPI_RESIDUAL: return launch1<K, K, bf16_t, VITK_EPI_RESIDUAL, -1>(a, grid, st);
+				return d.act == VITK_ACT_GELU ? launch_bf16<K, K, VITK_EPI_ACT, VITK_ACT_GELU>(a, grid, st) : launch_bf16<K, K, VITK_EPI_ACT, -1>(a, grid, st);
+			case VITK_EPI_RESIDUAL: return launch_bf16<K, K, VITK_EPI_RESIDUAL, -1>(a, grid, st);
 			default: return VITK_ERR_UNSUPPORTED;
 		}
 	}
 	if (d.a_layout == K && d.b_layout == MN) {
 		switch (d.epilogue) {
-			case VITK_EPI_NONE: return launch1<K, MN, bf16_t, VITK_EPI_NONE, -1>(a, grid, st);
+			case VITK_EPI_NONE: return launch_bf16<K, MN, VITK_EPI_NONE, -1>(a, grid, st);
 			case VITK_EPI_ACTGRAD:
-				return d.act == VITK_ACT_GELU ? launch1<K, MN, bf16_t, VITK_EPI_ACTGRAD, VITK_ACT_GELU>(a, grid, st)
-											  : launch1<K, MN, bf16_t, VITK_EPI_ACTGRAD, -1>(a, grid, st);
+				return d.act == VITK_ACT_GELU ? launch_bf16<K, MN, VITK_EPI_ACTGRAD, VITK_ACT_GELU>(a, grid, st)
+											  : launch_bf16<K, MN, VITK_EPI_ACTGRAD, -1>(a, grid, st);
 			default: return VITK_ERR_UNSUPPORTED;
 		}
 	}
@@ -377,6 +711,10 @@ int vitk_gemm_bf16_256(const vitk_gemm_desc& d, hipStream_t st) {
 	a.vec4 = (d.N % 4 == 0) && (d.ldc % 4 == 0) && (d.ld_aux % 4 == 0) && (d.ld_out2 % 4 == 0) && al16(d.C) && al16(d.bias) && al16(d.gamma) && al16(d.pos) &&
 		al16(d.aux) && al16(d.out2);
 	a.vec8 = a.vec4 && (d.N % 8 == 0) && (d.ldc % 8 == 0) && (d.ld_out2 % 8 == 0);
+#ifdef VITK_GEMM_STAMPS
+	a.stamps = g_stamps;
+	a.stagger = g_stagger;
+#endif
 	if (a.splits > 1 && !d.accumulate) {
 		hipError_t e = hipMemset2DAsync(d.C, (size_t)d.ldc * sizeof(float), 0, (size_t)d.N * sizeof(float), (size_t)d.M, st);
 		if (e != hipSuccess) return VITK_ERR_HIP - (int)e;

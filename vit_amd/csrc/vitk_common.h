@@ -80,7 +80,7 @@ __device__ __forceinline__ float wave_max(float v) {
 // `e` returns exp(-u^2 / 2), which the derivative reuses.
 __device__ __forceinline__ float gelu_cdf(float u, float& e) {
 	const float x = fabsf(u) * 0.70710678118654752f;
-	const float t = __frcp_rn(fmaf(0.3275911f, x, 1.0f));
+	const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, x, 1.0f));  // one v_rcp_f32 (1 ulp), not the IEEE division sequence
 	e = __expf(-x * x);
 	float poly = fmaf(1.061405429f, t, -1.453152027f);
 	poly = fmaf(poly, t, 1.421413741f);
@@ -96,7 +96,7 @@ __device__ __forceinline__ float act_apply(float u, int act) {
 			float e;
 			return u * gelu_cdf(u, e);
 		}
-		case VITK_ACT_SILU: return u / (1.0f + __expf(-u));
+		case VITK_ACT_SILU: return u * __builtin_amdgcn_rcpf(1.0f + __expf(-u));
 		case VITK_ACT_RELU: return fmaxf(u, 0.0f);
 		case VITK_ACT_RELU6: return fminf(fmaxf(u, 0.0f), 6.0f);
 		default: return u;
@@ -110,7 +110,7 @@ __device__ __forceinline__ float act_deriv(float u, int act) {
 			return fmaf(u * 0.39894228040143268f, e, cdf);
 		}
 		case VITK_ACT_SILU: {
-			float s = 1.0f / (1.0f + __expf(-u));
+			float s = __builtin_amdgcn_rcpf(1.0f + __expf(-u));
 			return s * (1.0f + u * (1.0f - s));
 		}
 		case VITK_ACT_RELU: return u > 0.0f ? 1.0f : 0.0f;
