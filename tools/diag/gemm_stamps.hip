@@ -48,6 +48,16 @@ int main(int argc, char** argv) {
 	}
 	std::vector<long long> h(nblk * rounds * 8);
 	hipMemcpy(h.data(), g_stamps, h.size() * 8, hipMemcpyDeviceToHost);
+	if (getenv("PP_SECTIONS")) {
+		// ping-pong kernel: shader-clock stamps of one K step of workgroup 0, per wave, at every barrier
+		for (int w = 0; w < 8; ++w) {
+			const long long* q = &h[w * 16];
+			printf("wave %d:", w);
+			for (int i = 1; i < 5; ++i) printf(" %5lld", q[i] - q[i - 1]);
+			printf("   | K step %lld cycles, start offset %lld\n", q[4] - q[0], q[0] - h[0]);
+		}
+		return 0;
+	}
 	long long tmin = -1, tmax = 0;
 	for (int b = 0; b < nblk; ++b)
 		for (int r = 0; r < rounds; ++r) {
