@@ -58,12 +58,10 @@ __device__ __forceinline__ bf16x8 read_frag(const char* tile, int base, int s, i
 // (the empty asm keeps the compiler from hoisting 16 loop-invariant address registers into the MFMA loop, where the
 // accumulators leave no room for them).
 template <int LAYOUT>
-__device__ __forceinline__ void stage_tile(char* tile, const bf16_t* __restrict__ base, int64_t ld, int64_t mn0, int64_t mn_total, int k0, int wave, int lane) {
+__device__ __forceinline__ void stage_piece(char* tile, const bf16_t* __restrict__ base, int64_t ld, int64_t mn0, int64_t mn_total, int k0, int piece, int lane) {
 	asm volatile("" : "+v"(lane));
 	const int ldi = (int)ld;
-#pragma unroll
-	for (int j = 0; j < 4; ++j) {
-		const int piece = 4 * wave + j;
+	{
 		const char* src;
 		if (LAYOUT == VITK_K_MAJOR) {
 			const int r = lane >> 3;  // == row & 7
@@ -87,6 +85,12 @@ __device__ __forceinline__ void stage_tile(char* tile, const bf16_t* __restrict_
 	}
 }
 
+template <int LAYOUT>
+__device__ __forceinline__ void stage_tile(char* tile, const bf16_t* __restrict__ base, int64_t ld, int64_t mn0, int64_t mn_total, int k0, int wave, int lane) {
+#pragma unroll
+	for (int j = 0; j < 4; ++j) stage_piece<LAYOUT>(tile, base, ld, mn0, mn_total, k0, 4 * wave + j, lane);
+}
+
 // Compile-time loop: the body sees its index as a constant, so accumulator arrays indexed by it can never become
 // runtime-indexed (which would move them to scratch memory) even when the optimizer declines to unroll a large body.
 template <int I, int N, typename F>
@@ -102,8 +106,13 @@ __device__ __forceinline__ void static_for(F&& f) {
 // (left alone, the compiler issues each read right before its first use and the MFMA pipe idles for the LDS latency).
 // Measured on the ViT-B/16 shapes: +5..15 % with a K-major A operand; with an MN-major A operand (two transposing
 // reads per fragment, weight-gradient GEMMs) the compiler's own order is 3 % faster and is kept.
-template <int ALAYOUT, int BLAYOUT>
-__device__ __forceinline__ void mma_stage(const char* sa, const char* sb, f32x4 (&acc)[8][4], int wm, int wn, int lane) {
+struct NoDma {
+	__device__ __forceinline__ void operator()(int) const {}
+};
+
+// `dma(j)`, j = 0..7: issues the j-th LDS-DMA request of the next K step; they go out one per two MFMA groups.
+template <int ALAYOUT, int BLAYOUT, bool SPREAD_DMA = false, typename DMA = NoDma>
+__device__ __forceinline__ void mma_stage(const char* sa, const char* sb, f32x4 (&acc)[8][4], int wm, int wn, int lane, DMA&& dma = NoDma{}) {
 	if constexpr (ALAYOUT == VITK_K_MAJOR) {
 		constexpr int RB = BLAYOUT == VITK_K_MAJOR ? 1 : 2;  // LDS reads per B fragment
 		bf16x8 wf[2][4], xf[3];
@@ -113,6 +122,7 @@ __device__ __forceinline__ void mma_stage(const char* sa, const char* sb, f32x4 
 		xf[1] = read_frag<ALAYOUT>(sa, wm + 16, 0, lane);
 		static_for<0, 16>([&](auto gc) {
 			constexpr int g = decltype(gc)::value, s = g >> 3, i = g & 7;
+			if constexpr (SPREAD_DMA && (g & 1) == 0) dma(g >> 1);
 			if constexpr (g + 2 < 16) xf[(g + 2) % 3] = read_frag<ALAYOUT>(sa, wm + 16 * ((g + 2) & 7), (g + 2) >> 3, lane);
 			if constexpr (g == 4) {
 #pragma unroll
@@ -126,10 +136,15 @@ __device__ __forceinline__ void mma_stage(const char* sa, const char* sb, f32x4 
 		static_for<0, 16>([&](auto gc) {
 			constexpr int g = decltype(gc)::value;
 			constexpr int reads = (g + 2 < 16 ? 1 : 0) + (g == 4 ? 4 * RB : 0);
+			if constexpr (SPREAD_DMA && (g & 1) == 0) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
 			if constexpr (reads > 0) __builtin_amdgcn_sched_group_barrier(0x100, reads, 0);
 			__builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
 		});
 	} else {
+		if constexpr (SPREAD_DMA) {
+#pragma unroll
+			for (int j = 0; j < 8; ++j) dma(j);
+		}
 #pragma unroll
 		for (int s = 0; s < 2; ++s) {
 			bf16x8 xf[8], wf[4];
@@ -572,16 +587,22 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_256p_kernel(BigArgs a) 
 			const char* sa = smem + (par ? BUF1 : 0);
 			const char* sb = sa + TILE_BYTES;
 			char* da = smem + (par ? 0 : BUF1);
-			if (t + 1 < nt) {
-				const int k0 = (t + 1) * BK;
-				stage_tile<ALAYOUT>(da, A, g.lda, m0, g.M, k0, wave, lane);
-				stage_tile<BLAYOUT>(da + TILE_BYTES, B, g.ldb, n0, g.N, k0, wave, lane);
-			} else {
-				nxt = tile_of(round + 1, nm0, nn0);
-				stage_tile<ALAYOUT>(da, A, g.lda, nm0, g.M, 0, wave, lane);
-				stage_tile<BLAYOUT>(da + TILE_BYTES, B, g.ldb, nn0, g.N, 0, wave, lane);
+			const bool last = t + 1 == nt;
+			if (last) nxt = tile_of(round + 1, nm0, nn0);
+			const int64_t sm0 = last ? nm0 : m0, sn0 = last ? nn0 : n0;
+			const int sk0 = last ? 0 : (t + 1) * BK;
+			// Issue of the 8 LDS-DMA requests of the next K step: spread between the MFMA groups when B is MN-major
+			// (measured +5..9 % there), all up front when both operands are K-major (spreading costs registers and is
+			// neutral to slightly negative there).
+			constexpr bool SPREAD = BLAYOUT == VITK_MN_MAJOR;
+			if constexpr (!SPREAD) {
+				stage_tile<ALAYOUT>(da, A, g.lda, sm0, g.M, sk0, wave, lane);
+				stage_tile<BLAYOUT>(da + TILE_BYTES, B, g.ldb, sn0, g.N, sk0, wave, lane);
 			}
-			mma_stage<ALAYOUT, BLAYOUT>(sa, sb, acc, wm, wn, lane);
+			mma_stage<ALAYOUT, BLAYOUT, SPREAD>(sa, sb, acc, wm, wn, lane, [&](int j) {
+				if (j & 1) stage_piece<BLAYOUT>(da + TILE_BYTES, B, g.ldb, sn0, g.N, sk0, 4 * wave + (j >> 1), lane);
+				else stage_piece<ALAYOUT>(da, A, g.lda, sm0, g.M, sk0, 4 * wave + (j >> 1), lane);
+			});
 			par ^= 1;
 		}
 		STAMP(2);
@@ -599,243 +620,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_256p_kernel(BigArgs a) 
 		have = nxt;
 	}
 	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the last (unused) DMA must not outlive the workgroup's LDS
-}
-
-// ---- ping-pong persistent kernel (K-major operands, bf16 output) -----------------------------------------------------
-// Same tile, same LDS images and same epilogue as the persistent kernel above, but the eight waves run as two groups of
-// four (waves 0-3: rows 0-127, waves 4-7: rows 128-255; one wave of each group per SIMD) that are one section out of
-// step: every K step is cut into four {load section, MFMA section} pairs separated by raw s_barriers, and while one
-// group issues the 16 MFMAs of its section the other group issues its LDS reads and LDS-DMA requests, so the matrix
-// pipe of every SIMD always has one wave feeding it.  The LDS-DMA requests of K step t+1 are issued during K step t in
-// the order their data is needed (A rows 0-63 / B rows 0-31 of each wave tile first, then B rows 32-63, then A rows
-// 64-127) and retired with counted s_waitcnt vmcnt, one load section ahead of the section that reads them; a load
-// section also retires its own LDS reads (lgkmcnt(0)) before its barrier, so a buffer is never re-staged under a read.
-//
-//   group 0:  L0 | M0 | L1 | M1 | L2 | M2 | L3 | M3 | ... | M3 | idle | EPI L0' | M0' | ...
-//   group 1:  -- | L0 | M0 | L1 | M1 | L2 | M2 | L3 | ... | L3 | M3   | EPI     | L0' | ...
-//
-//   L0: read A0 (8 fragments) + B0 (4)         M0: A0 x B0      DMA(t+1), one request per section and wave:
-//   L1: read B1 (4)                            M1: A0 x B1        L0 A0  M0 A0  L1 B0  M1 B0  L2 B1  M2 B1  L3 A1  M3 A1
-//   L2: read A1 (8, over A0's registers)       M2: A1 x B1      waits: vmcnt(3) at the end of L3 (A0, B0 of t+1 landed),
-//   L3: -                                      M3: A1 x B0        of L0 (B1 of this step) and of L1 (A1 of this step)
-struct TileWalk {
-	int ntiles, nblk, xcd, idx, tiles_m, tiles_n;
-	// tile of this workgroup in a round: consecutive tiles (in grouped order) go to workgroups that share an XCD
-	__device__ __forceinline__ bool at(int round, int64_t& m0, int64_t& n0) const {
-		constexpr int GM = 4;
-		const int per_group = GM * tiles_n;
-		const int base = round * nblk;
-		const int n = min(nblk, ntiles - base);
-		if (n <= 0) return false;
-		const int q = n >> 3, r = n & 7;
-		if (idx >= q + (xcd < r ? 1 : 0)) return false;
-		const int wg = base + (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-		const int group = wg / per_group;
-		const int first_m = group * GM;
-		const int gsz = min(tiles_m - first_m, GM);
-		m0 = (int64_t)(first_m + (wg % per_group) % gsz) * BM;
-		n0 = (int64_t)((wg % per_group) / gsz) * BN;
-		return true;
-	}
-};
-
-// LDS-DMA of ONE 1-KiB piece (8 rows x 64 k) of a K-major operand tile; addressing as in stage_tile.
-__device__ __forceinline__ void dma_piece_k(char* tile, const bf16_t* __restrict__ base, int64_t ld, int64_t mn0, int64_t mn_total, int k0, int piece, int lane) {
-	asm volatile("" : "+v"(lane));
-	const int r = lane >> 3;
-	const int chunk = (lane & 7) ^ r;
-	int64_t rowbase = mn0 + 8 * piece;
-	if (rowbase > mn_total - 1) rowbase = mn_total - 1;
-	const int rlim = (int)(mn_total - 1 - rowbase);
-	const int rr = r < rlim ? r : rlim;
-	const uint32_t voff = (uint32_t)(rr * (int)ld + 8 * chunk) * 2u;
-	const char* src = reinterpret_cast<const char*>(base + rowbase * ld + k0) + voff;
-	__builtin_amdgcn_global_load_lds((gbl_void_p)src, (lds_void_p)(tile + piece * 1024), 16, 0, 0);
-}
-
-#define PP_BARRIER()                          \
-	do {                                      \
-		__builtin_amdgcn_sched_barrier(0);    \
-		__builtin_amdgcn_s_barrier();         \
-		__builtin_amdgcn_sched_barrier(0);    \
-	} while (0)
-#define PP_WAIT(what) asm volatile("s_waitcnt " what ::: "memory")
-#ifdef VITK_GEMM_STAMPS
-#define PP_STAMP(q) pp_ts[q] = (long long)__builtin_amdgcn_s_memtime()
-#else
-#define PP_STAMP(q)
-#endif
-
-template <int EPI, int ACT>
-__global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_pp_kernel(BigArgs a) {
-	extern __shared__ __attribute__((aligned(16))) char smem[];
-	const GemmDev& g = a.g;
-	const int tid = threadIdx.x, lane = tid & 63;
-	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-	const int grp = wave >> 2;
-	const int wm = grp * 128, wn = (wave & 3) * 64;
-	constexpr int K = VITK_K_MAJOR;
-	constexpr int BUF1 = 8 * EW_BYTES;  // [stage buffer 0: 64 KiB][4 KiB][stage buffer 1: 64 KiB], as above
-	TileWalk tw{a.tiles_m * a.tiles_n, (int)gridDim.x, (int)(blockIdx.x & 7), (int)(blockIdx.x >> 3), a.tiles_m, a.tiles_n};
-#ifdef VITK_GEMM_STAMPS
-	const bool dg_nodma = a.stagger & 1, dg_noread = a.stagger & 2, dg_nomma = a.stagger & 4, dg_relax = a.stagger & 8;
-#else
-	constexpr bool dg_nodma = false, dg_noread = false, dg_nomma = false, dg_relax = false;
-#endif
-	const int nt = (int)(g.K / BK);
-	const bf16_t* A = reinterpret_cast<const bf16_t*>(g.A);
-	const bf16_t* B = reinterpret_cast<const bf16_t*>(g.B);
-
-	// the 8 pieces this wave requests per K step, by the order their data is needed
-	int pA0[2], pA1[2], pB0[2], pB1[2];
-#pragma unroll
-	for (int e = 0; e < 2; ++e) {
-		const int c = 2 * wave + e;
-		pA0[e] = (c >> 3) * 16 + (c & 7);
-		pA1[e] = pA0[e] + 8;
-		pB0[e] = (c >> 2) * 8 + (c & 3);
-		pB1[e] = pB0[e] + 4;
-	}
-
-	int64_t m0 = 0, n0 = 0;
-	bool have = tw.at(0, m0, n0);
-	if (!have) return;
-#pragma unroll
-	for (int e = 0; e < 2; ++e) {
-		dma_piece_k(smem, A, g.lda, m0, g.M, 0, pA0[e], lane);
-		dma_piece_k(smem, A, g.lda, m0, g.M, 0, pA1[e], lane);
-		dma_piece_k(smem + TILE_BYTES, B, g.ldb, n0, g.N, 0, pB0[e], lane);
-		dma_piece_k(smem + TILE_BYTES, B, g.ldb, n0, g.N, 0, pB1[e], lane);
-	}
-	PP_WAIT("vmcnt(0)");
-	PP_BARRIER();
-	if (grp == 1) PP_BARRIER();  // group 1 runs one section behind group 0 from here on
-
-	int cur = 0;  // buffer of the current K step
-	for (int round = 0; have; ++round) {
-		f32x4 acc[8][4];
-#pragma unroll
-		for (int i = 0; i < 8; ++i)
-#pragma unroll
-			for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-		int64_t nm0 = m0, nn0 = n0;  // after the last tile: re-fetch this tile's first K step (nobody reads it)
-		const bool nxt = tw.at(round + 1, nm0, nn0);
-
-		for (int t = 0; t < nt; ++t) {
-			const char* sa = smem + (cur ? BUF1 : 0);
-			const char* sb = sa + TILE_BYTES;
-			char* da = smem + (cur ? 0 : BUF1);
-			char* db = da + TILE_BYTES;
-			const bool last = t + 1 == nt;
-			const int64_t sm0 = last ? nm0 : m0, sn0 = last ? nn0 : n0;
-			const int sk0 = last ? 0 : (t + 1) * BK;
-			bf16x8 xA[4][2], xB[4][2];
-#ifdef VITK_GEMM_STAMPS
-			long long pp_ts[9];
-#endif
-			auto read_a = [&](int half) {
-				if (dg_noread) return;
-#pragma unroll
-				for (int s = 0; s < 2; ++s)
-#pragma unroll
-					for (int i = 0; i < 4; ++i) xA[i][s] = read_frag<K>(sa, wm + 64 * half + 16 * i, s, lane);
-			};
-			auto read_b = [&](auto hc) {
-				constexpr int half = decltype(hc)::value;
-				if (dg_noread) return;
-#pragma unroll
-				for (int s = 0; s < 2; ++s)
-#pragma unroll
-					for (int jj = 0; jj < 2; ++jj) xB[2 * half + jj][s] = read_frag<K>(sb, wn + 32 * half + 16 * jj, s, lane);
-			};
-			// 32 MFMAs (one half of the wave's rows x all its columns x both 32-deep halves of the K step); the LDS-DMA
-			// requests of the section go out between MFMAs, not in a burst
-			auto mma = [&](auto ic, auto&& dma0, auto&& dma1, auto&& dma2) {
-				constexpr int IH = decltype(ic)::value;
-				if (dg_nomma) {
-					dma0();
-					dma1();
-					dma2();
-					return;
-				}
-				__builtin_amdgcn_s_setprio(1);
-				static_for<0, 2>([&](auto sc) {
-					constexpr int s2 = decltype(sc)::value;
-					static_for<0, 4>([&](auto iic) {
-						constexpr int i = decltype(iic)::value;
-						static_for<0, 4>([&](auto jc) {
-							constexpr int j = decltype(jc)::value;
-							acc[4 * IH + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xB[j][s2], xA[i][s2], acc[4 * IH + i][j], 0, 0, 0);
-						});
-						if constexpr (i == 1 || (s2 == 0 && i == 3)) {
-							__builtin_amdgcn_sched_barrier(0);
-							if constexpr (s2 == 0 && i == 1) dma0();
-							if constexpr (s2 == 0 && i == 3) dma1();
-							if constexpr (s2 == 1 && i == 1) dma2();
-							__builtin_amdgcn_sched_barrier(0);
-						}
-					});
-				});
-				__builtin_amdgcn_s_setprio(0);
-			};
-			using I0 = std::integral_constant<int, 0>;
-			using I1 = std::integral_constant<int, 1>;
-			auto none = [] {};
-
-			PP_STAMP(0);
-			// L0 / M0: rows 0-63 of the wave tile
-			read_b(I0{});
-			read_b(I1{});
-			read_a(0);
-			if (!dg_nodma) {
-				dma_piece_k(db, B, g.ldb, sn0, g.N, sk0, pB0[0], lane);
-				dma_piece_k(db, B, g.ldb, sn0, g.N, sk0, pB0[1], lane);
-				dma_piece_k(db, B, g.ldb, sn0, g.N, sk0, pB1[0], lane);
-			}
-			if (t != 0) PP_WAIT("vmcnt(3)");  // the A1 pieces of this K step (requested in the previous M1) have landed
-			PP_WAIT("lgkmcnt(0)");
-			PP_BARRIER();
-			PP_STAMP(1);
-			mma(I0{}, [&] { if (!dg_nodma) dma_piece_k(db, B, g.ldb, sn0, g.N, sk0, pB1[1], lane); },
-				[&] { if (!dg_nodma) dma_piece_k(da, A, g.lda, sm0, g.M, sk0, pA0[0], lane); },
-				[&] { if (!dg_nodma) dma_piece_k(da, A, g.lda, sm0, g.M, sk0, pA0[1], lane); });
-			PP_BARRIER();
-			PP_STAMP(2);
-			// L1 / M1: rows 64-127
-			read_a(1);
-			PP_WAIT("vmcnt(0)");  // B and A0 of the next K step (requested one section or more ago) have landed
-			PP_WAIT("lgkmcnt(0)");
-			PP_BARRIER();
-			PP_STAMP(3);
-			mma(I1{}, [&] { if (!dg_nodma) dma_piece_k(da, A, g.lda, sm0, g.M, sk0, pA1[0], lane); },
-				[&] { if (!dg_nodma) dma_piece_k(da, A, g.lda, sm0, g.M, sk0, pA1[1], lane); }, none);
-			PP_BARRIER();
-			PP_STAMP(4);
-#ifdef VITK_GEMM_STAMPS
-			if (a.stamps != nullptr && blockIdx.x == 0 && round == 1 && t == 5 && lane == 0) {
-#pragma unroll
-				for (int q = 0; q < 5; ++q) a.stamps[wave * 16 + q] = pp_ts[q];
-			}
-#endif
-			cur ^= 1;
-		}
-
-		if (grp == 0) PP_BARRIER();  // group 0 waits one section: both groups run the epilogue together
-		// `cur` now names the buffer the next tile's first K step is in; the other one (last read two or more sections
-		// ago by either group) takes the epilogue image
-		const bool full = a.vec8 && n0 + wn + 64 <= g.N && m0 + wm + 128 <= g.M;
-		EpiRegs er;
-		epilogue_prefetch<EPI>(a, er, full, m0 + wm, n0 + wn, lane);
-		PP_WAIT("vmcnt(0)");  // also retires the B1 / A1 requests of the next K step: its first sections need no waits
-		float* img = reinterpret_cast<float*>(smem + (cur ? 0 : STAGE_BYTES) + wave * EW_BYTES);
-		epilogue_wave_private<EPI, ACT>(a, acc, er, full, img, m0 + wm, n0 + wn, lane);
-		if (grp == 1) PP_BARRIER();
-		m0 = nm0;
-		n0 = nn0;
-		have = nxt;
-	}
-	if (grp == 0) PP_BARRIER();
-	PP_WAIT("vmcnt(0)");  // the last (unused) DMA must not outlive the workgroup's LDS
 }
 
 template <int AL, int BL, typename TOUT, int EPI, int ACT>
@@ -877,30 +661,11 @@ int launchp(const BigArgs& a, hipStream_t st) {
 	return VITK_OK;
 }
 
-template <int EPI, int ACT>
-int launchpp(const BigArgs& a, hipStream_t st) {
-	static bool attr = false;
-	if (!attr) {
-		hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_pp_kernel<EPI, ACT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSP_BYTES);
-		if (e != hipSuccess) return VITK_ERR_HIP - (int)e;
-		attr = true;
-	}
-	hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI, ACT>), dim3((unsigned)persistent_blocks()), dim3(NTHREADS), LDSP_BYTES, st, a);
-	VITK_CHECK_LAUNCH();
-	return VITK_OK;
-}
-
 // bf16 outputs: persistent kernel when there is more than one tile per CU, else one workgroup per tile
 template <int AL, int BL, int EPI, int ACT>
 int launch_bf16(const BigArgs& a, dim3 grid, hipStream_t st) {
 	static const bool no_persist = std::getenv("VITK_NO_PERSISTENT") != nullptr;
-	static const bool no_pingpong = std::getenv("VITK_NO_PINGPONG") != nullptr;
-	if (!no_persist && a.splits == 1 && (int64_t)a.tiles_m * a.tiles_n > persistent_blocks()) {
-		if constexpr (AL == VITK_K_MAJOR && BL == VITK_K_MAJOR) {
-			if (!no_pingpong) return launchpp<EPI, ACT>(a, st);
-		}
-		return launchp<AL, BL, EPI, ACT>(a, st);
-	}
+	if (!no_persist && a.splits == 1 && (int64_t)a.tiles_m * a.tiles_n > persistent_blocks()) return launchp<AL, BL, EPI, ACT>(a, st);
 	return launch1<AL, BL, bf16_t, EPI, ACT>(a, grid, st);
 }
 
