@@ -151,6 +151,10 @@ int vitk_attention_bwd(const void* dout, const void* q, const void* k, const voi
  */
 /* dst[i] = (dst_dtype) src[i] */
 int vitk_cast(const void* src, void* dst, int64_t n, int src_dtype, int dst_dtype, void* stream);
+/* y[c*ldy + r] = x[r*ldx + c] for r < rows, c < cols.  No counterpart op in the reference: it keeps a transposed
+ * bf16 copy of a Linear weight so that the input-gradient GEMM of autograd (the dy @ W of nn.Linear's backward,
+ * reached from layers/transformers.py:43-54 and layers/attention.py:36-59) reads both operands K-major. */
+int vitk_transpose(const void* x, void* y, int64_t rows, int64_t cols, int64_t ldx, int64_t ldy, int dtype, void* stream);
 /* out[n] (+)= sum_m x[m*ld + n]  — bias gradient of a Linear (autograd of addmm) */
 int vitk_colsum(const void* x, float* out, int64_t M, int64_t N, int64_t ld, int accumulate, int dtype, void* stream);
 /* Gated FFN (layers/transformers.py:48-50): u = [gate | up] with row stride ld_u, a = gate * act(up). */

@@ -137,6 +137,45 @@ def test_gemm_more_tiles_than_cus(gpu, act):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("rows,cols", [(768, 3072), (65, 130), (1, 7), (200, 64)])
+def test_transpose(gpu, dtype, rows, cols):
+	from vit_amd import ops
+	x, _ = rnd((rows, cols), dtype, gpu, seed=11)
+	y = ops.transpose(x)
+	assert y.shape == (cols, rows) and torch.equal(y.cpu(), x.cpu().t().contiguous())  # a copy: bit-exact
+	# strided source (a column block of a wider matrix)
+	wide, _ = rnd((rows, cols + 8), dtype, gpu, seed=12)
+	assert torch.equal(ops.transpose(wide[:, 3:3 + cols]).cpu(), wide.cpu()[:, 3:3 + cols].t().contiguous())
+
+
+def test_dgrad_transposed_weight_path(gpu):
+	"""Many-token bf16 input gradients run on a cached transposed weight copy: same result as the direct path, and the
+	cache follows weight updates (version bump / weights_changed())."""
+	from vit_amd import ops
+	import vit_amd._lib as L
+	M, N, K = 4500, 320, 384  # dy [M, N], w [N, K]
+	dy, dyr = rnd((M, N), torch.bfloat16, gpu, seed=1)
+	w, wr = rnd((N, K), torch.bfloat16, gpu, 0.1, seed=2)
+	pre, _ = rnd((M, K), torch.bfloat16, gpu, seed=3)
+	a = ops.linear_dgrad(dy, w)
+	assert relerr(a, dyr @ wr) < TOL[torch.bfloat16]
+	ops.DGRAD_TRANSPOSED_WEIGHTS = False
+	try:
+		b = ops.linear_dgrad(dy, w)
+		b2 = ops.linear_dgrad(dy, w, act=L.ACT_GELU, pre=pre)
+	finally:
+		ops.DGRAD_TRANSPOSED_WEIGHTS = True
+	assert relerr(a, b.cpu().double()) < 1e-2  # two kernels, same bf16 operands: accumulation order only
+	a2 = ops.linear_dgrad(dy, w, act=L.ACT_GELU, pre=pre)
+	assert relerr(a2, b2.cpu().double()) < 1e-2
+	w.mul_(2.0)  # in-place update through torch bumps the version: the cached transpose must not be reused
+	assert relerr(ops.linear_dgrad(dy, w), 2.0 * (dyr @ wr)) < TOL[torch.bfloat16]
+	L.check(L.load().vitk_cast(L.ptr((wr * 3.0).to(torch.bfloat16).to(gpu)), L.ptr(w), w.numel(), L.BF16, L.BF16, L.stream()))  # behind torch's back
+	ops.weights_changed()
+	assert relerr(ops.linear_dgrad(dy, w), 3.0 * (dyr @ wr)) < TOL[torch.bfloat16]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("kind", ["layernorm", "rmsnorm"])
 @pytest.mark.parametrize("rows,d", [(37, 768), (9, 192), (5, 40), (3, 50), (11, 2048)])
 def test_norms(gpu, dtype, kind, rows, d):

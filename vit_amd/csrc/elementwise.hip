@@ -351,6 +351,38 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
 			return VITK_ERR_DTYPE;              \
 	} while (0)
 
+// y[c][r] = x[r][c]: 64x64 tiles through LDS (row pitch 65 elements: conflict-free both ways), 256 threads.
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t rows, int64_t cols, int64_t ldx, int64_t ldy) {
+	__shared__ T tile[64][65];
+	const int64_t r0 = (int64_t)blockIdx.y * 64, c0 = (int64_t)blockIdx.x * 64;
+	const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+#pragma unroll 4
+	for (int i = ty; i < 64; i += 4) {
+		const int64_t r = r0 + i, c = c0 + tx;
+		if (r < rows && c < cols) tile[i][tx] = x[r * ldx + c];
+	}
+	__syncthreads();
+#pragma unroll 4
+	for (int i = ty; i < 64; i += 4) {
+		const int64_t c = c0 + i, r = r0 + tx;
+		if (r < rows && c < cols) y[c * ldy + r] = tile[tx][i];
+	}
+}
+
+extern "C" int vitk_transpose(const void* x, void* y, int64_t rows, int64_t cols, int64_t ldx, int64_t ldy, int dtype, void* stream) {
+	VITK_REQUIRE(x && y, VITK_ERR_NULL);
+	VITK_REQUIRE(rows >= 0 && cols >= 0 && ldx >= cols && ldy >= rows, VITK_ERR_SHAPE);
+	if (rows == 0 || cols == 0) return VITK_OK;
+	const int64_t gx = vitk_cdiv(cols, 64), gy = vitk_cdiv(rows, 64);
+	VITK_REQUIRE(gx < (1ll << 31) && gy < 65536, VITK_ERR_SHAPE);
+	DISPATCH_T(dtype, {
+		hipLaunchKernelGGL((transpose_kernel<T>), dim3((unsigned)gx, (unsigned)gy), dim3(256), 0, (hipStream_t)stream, (const T*)x, (T*)y, rows, cols, ldx, ldy);
+		VITK_CHECK_LAUNCH();
+		return VITK_OK;
+	});
+}
+
 extern "C" int vitk_cast(const void* src, void* dst, int64_t n, int src_dtype, int dst_dtype, void* stream) {
 	VITK_REQUIRE(src && dst, VITK_ERR_NULL);
 	VITK_REQUIRE(n >= 0, VITK_ERR_SHAPE);

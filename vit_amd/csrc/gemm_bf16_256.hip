@@ -201,12 +201,18 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_256_kernel(BigArgs a) {
 	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 	const int wm = (wave >> 2) * 128, wn = (wave & 3) * 64;
 
-	const int nwg = a.tiles_m * a.tiles_n;
+	// 1-D grid over (K slice, tile), K slice outermost: workgroups that share an XCD (equal blockIdx % 8) get a
+	// contiguous run of that order, i.e. neighbouring tiles of the SAME K slice, whose operand panels they then share
+	// through the XCD's L2.
+	const int ntile = a.tiles_m * a.tiles_n;
+	const int nwg = ntile * a.splits;
 	int wg = blockIdx.x;
 	{
 		const int q = nwg >> 3, r = nwg & 7, xcd = wg & 7, idx = wg >> 3;
 		wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 	}
+	const int split = wg / ntile;
+	wg -= split * ntile;
 	constexpr int GM = 4;
 	const int per_group = GM * a.tiles_n;
 	const int group = wg / per_group;
@@ -216,7 +222,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_256_kernel(BigArgs a) {
 	const int tn = (wg % per_group) / gsz;
 	int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
 
-	const int k_begin = blockIdx.y * a.k_per_split;
+	const int k_begin = split * a.k_per_split;
 	const int k_end = min((int)g.K, k_begin + a.k_per_split);
 	const int nt = (k_end - k_begin) / BK;
 
@@ -671,7 +677,8 @@ int launch_bf16(const BigArgs& a, dim3 grid, hipStream_t st) {
 
 // Variants instantiated (what the ViT / CvT training step uses); any other combination returns VITK_ERR_UNSUPPORTED
 // and runs on the 128x128 kernel with its run-time epilogue.
-//   (K, K)   forward:  plain (bf16 / f32), bias + activation (+ pre-activation), bias + LayerScale + residual
+//   (K, K)   forward:  plain (bf16 / f32), bias + activation (+ pre-activation), bias + LayerScale + residual;
+//            dgrad against a transposed weight copy: plain, activation derivative
 //   (K, MN)  dgrad:    plain, activation derivative
 //   (MN, MN) wgrad:    f32 (plain or split-K atomics)
 int launch_variant(const BigArgs& a, const vitk_gemm_desc& d, dim3 grid, hipStream_t st) {
@@ -690,6 +697,8 @@ int launch_variant(const BigArgs& a, const vitk_gemm_desc& d, dim3 grid, hipStre
 			case VITK_EPI_ACT:
 				return d.act == VITK_ACT_GELU ? launch_bf16<K, K, VITK_EPI_ACT, VITK_ACT_GELU>(a, grid, st) : launch_bf16<K, K, VITK_EPI_ACT, -1>(a, grid, st);
 			case VITK_EPI_RESIDUAL: return launch_bf16<K, K, VITK_EPI_RESIDUAL, -1>(a, grid, st);
+			case VITK_EPI_ACTGRAD:  // input gradient against a transposed weight copy
+				return d.act == VITK_ACT_GELU ? launch_bf16<K, K, VITK_EPI_ACTGRAD, VITK_ACT_GELU>(a, grid, st) : launch_bf16<K, K, VITK_EPI_ACTGRAD, -1>(a, grid, st);
 			default: return VITK_ERR_UNSUPPORTED;
 		}
 	}
@@ -743,5 +752,5 @@ int vitk_gemm_bf16_256(const vitk_gemm_desc& d, hipStream_t st) {
 		hipError_t e = hipMemset2DAsync(d.C, (size_t)d.ldc * sizeof(float), 0, (size_t)d.N * sizeof(float), (size_t)d.M, st);
 		if (e != hipSuccess) return VITK_ERR_HIP - (int)e;
 	}
-	return launch_variant(a, d, dim3((unsigned)tiles, (unsigned)a.splits), st);
+	return launch_variant(a, d, dim3((unsigned)(tiles * a.splits)), st);
 }

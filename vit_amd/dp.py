@@ -148,6 +148,7 @@ class FlatAdamW:
 			self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay, self.step_count, grad_scale, L.stream()))
 		if self.shadow is None:
 			ops.invalidate_casts()  # the kernel writes the parameters without bumping their version counters
+		ops.weights_changed()  # cached transposed weight copies are stale now
 
 
 class Trainer:

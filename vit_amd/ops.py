@@ -58,6 +58,7 @@ def register_shadow(param, shadow_bf16):
 def invalidate_casts():
 	"""Drop cached casts (call after modifying parameters through anything that does not bump their version)."""
 	_cast_cache.clear()
+	_wt_cache.clear()
 
 
 def weight_as(w, dtype):
@@ -79,6 +80,39 @@ def weight_as(w, dtype):
 	return out
 
 
+def transpose(x):
+	"""Contiguous transpose of a 2-D tensor through vitk_transpose."""
+	assert x.dim() == 2 and x.stride(1) == 1
+	rows, cols = x.shape
+	y = torch.empty((cols, rows), dtype=x.dtype, device=x.device)
+	L.check(L.load().vitk_transpose(L.ptr(x), L.ptr(y), rows, cols, x.stride(0), rows, L.dtype_code(x.dtype), L.stream()))
+	return y
+
+
+_wt_cache = {}  # id(compute-dtype weight) -> (weakref, key, transposed copy)
+_weights_epoch = 0
+
+
+def weights_changed():
+	"""Tell the caches that weight copies were rewritten behind torch's back (the fused optimizer kernel updates the
+	bf16 shadows in place without bumping a version counter)."""
+	global _weights_epoch
+	_weights_epoch += 1
+
+
+def weight_t(wc):
+	"""Transposed copy [in, out] of a weight `wc` [out, in] that is already in the compute dtype (what weight_as
+	returned); cached until the weight changes."""
+	key = (wc._version, wc.data_ptr(), _weights_epoch)
+	hit = _wt_cache.get(id(wc))
+	if hit is not None and hit[0]() is wc and hit[1] == key:
+		return hit[2]
+	out = transpose(wc)
+	wid = id(wc)
+	_wt_cache[wid] = (weakref.ref(wc, lambda _r, wid=wid: _wt_cache.pop(wid, None)), key, out)
+	return out
+
+
 def f32(t):
 	"""float32 view/copy of a small parameter vector (norm weights, biases, LayerScale)."""
 	if t is None:
@@ -96,6 +130,7 @@ def grad_as(g, like):
 # raw kernels
 # --------------------------------------------------------------------------------------------------
 
+DGRAD_TRANSPOSED_WEIGHTS = True  # see linear_dgrad
 GEMM_PROFILE = None  # set to a list to collect (kernel label, flops, start event, end event) per launch
 
 
@@ -159,6 +194,15 @@ def linear_dgrad(dy, w, act=L.ACT_NONE, pre=None, out=None):
 	K = w.shape[1]
 	assert w.shape[0] == N and dy.stride(1) == 1 and w.is_contiguous()
 	dx = out if out is not None else torch.empty((M, K), dtype=dy.dtype, device=dy.device)
+	if DGRAD_TRANSPOSED_WEIGHTS and dy.dtype == torch.bfloat16 and M >= 4096 and N % 64 == 0 and K >= 256 and N >= 256:
+		# many tokens: a transposed copy of the weight (one small kernel per weight and optimizer step) makes both
+		# operands K-major, the layout the large-tile GEMM runs fastest on
+		wt = weight_t(w)
+		if pre is not None:
+			gemm(dy, wt, dx, M, K, N, dy.stride(0), N, dx.stride(0), epilogue=L.EPI_ACTGRAD, act=act, aux=pre, ld_aux=pre.stride(0))
+		else:
+			gemm(dy, wt, dx, M, K, N, dy.stride(0), N, dx.stride(0))
+		return dx
 	# sum over n: A = dy (n contiguous), B(n'=k, k'=n) = w[n, k] -> MN-major with ldb = K
 	if pre is not None:
 		gemm(dy, w, dx, M, K, N, dy.stride(0), K, dx.stride(0), b_layout=L.MN_MAJOR, epilogue=L.EPI_ACTGRAD, act=act, aux=pre, ld_aux=pre.stride(0))
