@@ -84,17 +84,20 @@ __global__ __launch_bounds__(256) void norm_fwd_kernel(const T* __restrict__ x, 
 	}
 }
 
+constexpr int BWD_THREADS = 256;  // 4 waves; at most 3 workgroups per CU are launched (register budget), so few workgroups add into dgamma / dbeta
+
 template <typename T, int VEC, int ITERS, bool RMS>
-__global__ __launch_bounds__(256) void norm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+__global__ __launch_bounds__(BWD_THREADS) void norm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
 	const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ rstd_in,
 	const T* __restrict__ dres, T* __restrict__ dx, float* dgamma, float* dbeta, int64_t rows, int d, float offset) {
 	extern __shared__ __attribute__((aligned(16))) float red[];  // [2][d]
 	const int lane = threadIdx.x & 63;
 	const int wave = threadIdx.x >> 6;
-	const int64_t nwaves = (int64_t)gridDim.x * 4;
+	constexpr int WAVES = BWD_THREADS / 64;
+	const int64_t nwaves = (int64_t)gridDim.x * WAVES;
 	const int nchunk = d / VEC;
 	const float inv_d = 1.0f / (float)d;
-	for (int i = threadIdx.x; i < 2 * d; i += 256) red[i] = 0.f;
+	for (int i = threadIdx.x; i < 2 * d; i += BWD_THREADS) red[i] = 0.f;
 	__syncthreads();
 
 	float gsc[ITERS][VEC];  // gamma (+offset) for this lane's columns
@@ -116,27 +119,51 @@ __global__ __launch_bounds__(256) void norm_bwd_kernel(const T* __restrict__ dy,
 			}
 		}
 	}
-	for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += nwaves) {
-		const float mu = RMS ? 0.f : mean[row];
-		const float rs = rstd_in[row];
-		float xh[ITERS][VEC], g[ITERS][VEC], rres[ITERS][VEC];
+	// The next row's operands are requested (as packed 16-byte registers) before this row is worked on: a wave keeps
+	// two rows of loads in flight, which is what it takes to cover the HBM latency at 4 waves per SIMD.
+	Pack<T, VEC> px[ITERS], pdy[ITERS], pres[ITERS];
+	float pmu = 0.f, prs = 0.f;
+	auto fetch = [&](int64_t row) {
+		if (!RMS) pmu = mean[row];
+		prs = rstd_in[row];
+#pragma unroll
+		for (int it = 0; it < ITERS; ++it) {
+			const int c = lane + it * 64;
+			if (c < nchunk) {
+				px[it] = *reinterpret_cast<const Pack<T, VEC>*>(x + row * d + c * VEC);
+				pdy[it] = *reinterpret_cast<const Pack<T, VEC>*>(dy + row * d + c * VEC);
+				if (dres != nullptr) pres[it] = *reinterpret_cast<const Pack<T, VEC>*>(dres + row * d + c * VEC);
+			}
+		}
+	};
+	const int64_t row0 = (int64_t)blockIdx.x * WAVES + wave;
+	if (row0 < rows) fetch(row0);
+	for (int64_t row = row0; row < rows; row += nwaves) {
+		const float mu = pmu, rs = prs;
+		float xh[ITERS][VEC], g[ITERS][VEC], rres[ITERS][VEC], dyv[ITERS][VEC];
+#pragma unroll
+		for (int it = 0; it < ITERS; ++it) {
+#pragma unroll
+			for (int j = 0; j < VEC; ++j) {
+				xh[it][j] = to_f32<T>(px[it].v[j]);
+				dyv[it][j] = to_f32<T>(pdy[it].v[j]);
+				rres[it][j] = dres != nullptr ? to_f32<T>(pres[it].v[j]) : 0.f;
+			}
+		}
+		if (row + nwaves < rows) fetch(row + nwaves);
 		float s1 = 0.f, s2 = 0.f;
 #pragma unroll
 		for (int it = 0; it < ITERS; ++it) {
 			const int c = lane + it * 64;
 			if (c < nchunk) {
-				float dyv[VEC];
-				load_vec<T, VEC>(x + row * d + c * VEC, xh[it]);
-				load_vec<T, VEC>(dy + row * d + c * VEC, dyv);
-				if (dres != nullptr) load_vec<T, VEC>(dres + row * d + c * VEC, rres[it]);  // issued with the other loads
 #pragma unroll
 				for (int j = 0; j < VEC; ++j) {
 					xh[it][j] = (xh[it][j] - mu) * rs;
-					g[it][j] = dyv[j] * gsc[it][j];
+					g[it][j] = dyv[it][j] * gsc[it][j];
 					s1 += g[it][j];
 					s2 += g[it][j] * xh[it][j];
-					accg[it][j] += dyv[j] * xh[it][j];
-					accb[it][j] += dyv[j];
+					accg[it][j] += dyv[it][j] * xh[it][j];
+					accb[it][j] += dyv[it][j];
 				}
 			} else {
 #pragma unroll
@@ -176,9 +203,13 @@ __global__ __launch_bounds__(256) void norm_bwd_kernel(const T* __restrict__ dy,
 		}
 	}
 	__syncthreads();
-	for (int i = threadIdx.x; i < d; i += 256) {
-		atomicAdd(&dgamma[i], red[i]);
-		if (!RMS) atomicAdd(&dbeta[i], red[d + i]);
+	// every workgroup starts at another column, so workgroups that finish together do not queue on the same addresses
+	const int rot = (int)((blockIdx.x * 61u) % (unsigned)d);
+	for (int i = threadIdx.x; i < d; i += BWD_THREADS) {
+		int c = i + rot;
+		if (c >= d) c -= d;
+		atomicAdd(&dgamma[c], red[c]);
+		if (!RMS) atomicAdd(&dbeta[c], red[d + c]);
 	}
 }
 
@@ -202,9 +233,9 @@ int launch_fwd(const NormArgs& a, hipStream_t st) {
 }
 template <typename T, int VEC, int ITERS, bool RMS>
 int launch_bwd(const NormArgs& a, hipStream_t st) {
-	int grid = (int)std::min<int64_t>(vitk_cdiv(a.rows, 4), 2048);
+	int grid = (int)std::min<int64_t>(vitk_cdiv(a.rows, BWD_THREADS / 64), 768);
 	size_t lds = (size_t)2 * a.d * sizeof(float);
-	hipLaunchKernelGGL((norm_bwd_kernel<T, VEC, ITERS, RMS>), dim3(grid), dim3(256), lds, st, (const T*)a.dy, (const T*)a.x, a.gamma, a.mean_in,
+	hipLaunchKernelGGL((norm_bwd_kernel<T, VEC, ITERS, RMS>), dim3(grid), dim3(BWD_THREADS), lds, st, (const T*)a.dy, (const T*)a.x, a.gamma, a.mean_in,
 		a.rstd_in, (const T*)a.dres, (T*)a.dx, a.dgamma, a.dbeta, a.rows, a.d, a.offset);
 	VITK_CHECK_LAUNCH();
 	return VITK_OK;
@@ -214,6 +245,18 @@ template <typename T, bool RMS, bool FWD>
 int dispatch(const NormArgs& a, bool vec_ok, hipStream_t st) {
 	constexpr int V = VecOf<T>::N;
 #define NORM_GO(VEC_, IT_) return FWD ? launch_fwd<T, VEC_, IT_, RMS>(a, st) : launch_bwd<T, VEC_, IT_, RMS>(a, st)
+	if (!FWD && vec_ok && a.d % (V / 2) == 0) {
+		// backward (register-heavy): if half-width accesses leave fewer lane slots idle (d = 768: 3 x 64 x 4 exactly,
+		// against 2 x 64 x 8 with a quarter idle), the smaller footprint keeps 4 waves per SIMD resident
+		constexpr int H = V / 2;
+		const int it_full = a.d % V == 0 ? (int)vitk_cdiv(a.d / V, 64) : 1 << 20;
+		const int it_half = (int)vitk_cdiv(a.d / H, 64);
+		if (it_half <= 3 && it_half * H < it_full * V) {
+			if (it_half <= 1) return launch_bwd<T, H, 1, RMS>(a, st);
+			if (it_half <= 2) return launch_bwd<T, H, 2, RMS>(a, st);
+			return launch_bwd<T, H, 3, RMS>(a, st);
+		}
+	}
 	if (vec_ok && a.d % V == 0) {
 		const int iters = (int)vitk_cdiv(a.d / V, 64);
 		if (iters <= 1) NORM_GO(V, 1);

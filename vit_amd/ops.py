@@ -253,11 +253,12 @@ def norm_bwd(dy, x, weight, mean, rstd, kind, unit_offset=True, dres=None):
 	rows, d = x.shape
 	assert dy.is_contiguous() and x.is_contiguous() and (dres is None or dres.is_contiguous())
 	dx = torch.empty_like(x)
-	dw = torch.zeros(d, dtype=torch.float32, device=x.device)
+	dwb = torch.zeros((2, d), dtype=torch.float32, device=x.device)  # one fill for both accumulators
+	dw = dwb[0]
 	lib = L.load()
 	dt = L.dtype_code(x.dtype)
 	if kind == "layernorm":
-		db = torch.zeros(d, dtype=torch.float32, device=x.device)
+		db = dwb[1]
 		L.check(lib.vitk_layernorm_bwd(L.ptr(dy), L.ptr(x), L.ptr(weight), L.ptr(mean), L.ptr(rstd), L.ptr(dres), L.ptr(dx), L.ptr(dw), L.ptr(db), rows, d, dt, L.stream()))
 		return dx, dw, db
 	L.check(lib.vitk_rmsnorm_bwd(L.ptr(dy), L.ptr(x), L.ptr(weight), L.ptr(rstd), L.ptr(dres), L.ptr(dx), L.ptr(dw), rows, d, int(unit_offset), dt, L.stream()))
