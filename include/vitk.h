@@ -102,6 +102,9 @@ typedef struct vitk_gemm_desc {
 	int64_t ld_aux;
 	void* out2;                /* [M, ld_out2] optional second output */
 	int64_t ld_out2;
+	float* a_colsum;           /* [M] or null; MN-major A only: a_colsum[m] += sum_k A(m,k), i.e. the bias gradient
+	                              (column sums of dy) that autograd's addmm backward forms next to dW = dy^T x.
+	                              ACCUMULATED into: the caller zeroes it. */
 } vitk_gemm_desc;
 
 int vitk_gemm(const vitk_gemm_desc* desc, void* stream);

@@ -137,6 +137,22 @@ def test_gemm_more_tiles_than_cus(gpu, act):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K", [(6400, 768, 512), (4099 * 8, 264, 320), (1000, 264, 192), (300, 130, 72), (197 * 8, 1000, 768)])
+def test_wgrad_with_bias_grad(gpu, dtype, M, N, K):
+	"""dw = dy^T x together with db = column sums of dy (what autograd's addmm backward produces), on every GEMM path:
+	large tiles with split-K (column sums fused into the kernel), 128x128 tiles and the float32 kernel (column-sum
+	kernel behind the GEMM)."""
+	from vit_amd import ops
+	dy, dyr = rnd((M, N), dtype, gpu, seed=1)
+	x, xr = rnd((M, K), dtype, gpu, seed=2)
+	dw, db = ops.linear_wgrad(dy, x, bias_grad=True)
+	tol = 1e-4 if dtype == torch.float32 else 1e-3  # float32 outputs: accumulation-order error only
+	assert relerr(dw, dyr.t() @ xr) < tol
+	assert relerr(db, dyr.sum(0)) < tol
+	assert relerr(ops.linear_wgrad(dy, x), dyr.t() @ xr) < tol  # and without the bias gradient
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("rows,cols", [(768, 3072), (65, 130), (1, 7), (200, 64)])
 def test_transpose(gpu, dtype, rows, cols):
 	from vit_amd import ops

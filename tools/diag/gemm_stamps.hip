@@ -39,7 +39,8 @@ int main(int argc, char** argv) {
 	hipEventCreate(&e1);
 	for (int it = 0; it < 3; ++it) {
 		hipEventRecord(e0, 0);
-		int rc = vitk_gemm_bf16_256(d, 0);
+		bool cs = false;
+		int rc = vitk_gemm_bf16_256(d, 0, &cs);
 		hipEventRecord(e1, 0);
 		hipDeviceSynchronize();
 		float ms;

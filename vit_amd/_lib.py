@@ -34,6 +34,7 @@ class GemmDesc(ctypes.Structure):
 		("bias", c_void_p), ("gamma", c_void_p), ("pos", c_void_p),
 		("aux", c_void_p), ("ld_aux", c_int64),
 		("out2", c_void_p), ("ld_out2", c_int64),
+		("a_colsum", c_void_p),
 	]
 
 

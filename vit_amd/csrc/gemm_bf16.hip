@@ -284,10 +284,11 @@ bool vitk_gemm_bf16_ok(const vitk_gemm_desc& d) {
 	return true;
 }
 
-int vitk_gemm_bf16(const vitk_gemm_desc& d, hipStream_t st) {
+int vitk_gemm_bf16(const vitk_gemm_desc& d, hipStream_t st, bool* colsum_done) {
 	static const bool big_tiles = getenv("VITK_NO_BIG_TILE") == nullptr;  // debugging / A-B switch
+	*colsum_done = false;
 	if (big_tiles && vitk_gemm_bf16_256_ok(d)) {
-		const int rc = vitk_gemm_bf16_256(d, st);
+		const int rc = vitk_gemm_bf16_256(d, st, colsum_done);
 		if (rc != VITK_ERR_UNSUPPORTED) return rc;
 	}
 	BfArgs a{};

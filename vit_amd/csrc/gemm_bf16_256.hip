@@ -164,6 +164,7 @@ struct BigArgs {
 	GemmDev g;
 	int tiles_m, tiles_n, splits, k_per_split;
 	int vec4, vec8;  // epilogue operands / outputs may be accessed 4-wide (8 / 16 bytes) resp. 8-wide (16 bytes bf16)
+	float* a_colsum;  // MN-major A: sum over k of A(m, k) is added here (bias gradient), or null
 #ifdef VITK_GEMM_STAMPS
 	long long* stamps;  // diagnostic builds only: [workgroup][round][8] timestamps of the persistent kernel
 	int stagger;        // diagnostic builds only: start delay step in 10 ns ticks
@@ -244,6 +245,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_256_kernel(BigArgs a) {
 	__syncthreads();  // with LDS-DMA in flight hipcc drains vmcnt(0) ahead of the barrier
 	STAMP(1);
 
+	// Column sums of an MN-major A (the bias gradient next to a weight gradient): the A tile of a K step is in LDS
+	// anyway; the tiles_n workgroups that share it take turns (K step kt belongs to the one with tn == kt % tiles_n),
+	// each of its 512 threads adds up 32 of the 64 rows of one column.
+	float csum = 0.f;
+	const bool do_colsum = ALAYOUT == VITK_MN_MAJOR && a.a_colsum != nullptr;
 	for (int t = 0; t < nt; ++t) {
 		const char* sa = smem + (t & 1) * STAGE_BYTES;
 		const char* sb = sa + TILE_BYTES;
@@ -253,10 +259,20 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_256_kernel(BigArgs a) {
 			stage_tile<ALAYOUT>(da, A, g.lda, m0, g.M, k0, wave, lane);
 			stage_tile<BLAYOUT>(da + TILE_BYTES, B, g.ldb, n0, g.N, k0, wave, lane);
 		}
+		if constexpr (ALAYOUT == VITK_MN_MAJOR) {
+			if (do_colsum && (k_begin / BK + t) % a.tiles_n == tn) {
+				const int c = tid & 255, kr0 = (tid >> 8) * 32;
+#pragma unroll 8
+				for (int kr = kr0; kr < kr0 + 32; ++kr) csum += (float)*reinterpret_cast<const bf16_t*>(sa + off_mn(kr, c >> 3) + (c & 7) * 2);
+			}
+		}
 		mma_stage<ALAYOUT, BLAYOUT>(sa, sb, acc, wm, wn, lane);
 		__syncthreads();  // next stage landed (vmcnt(0) drained by the fence) and everyone is done with this one
 	}
 
+	if constexpr (ALAYOUT == VITK_MN_MAJOR) {
+		if (do_colsum && m0 + (tid & 255) < g.M) atomicAdd(a.a_colsum + m0 + (tid & 255), csum);
+	}
 	STAMP(2);
 #ifdef VITK_GEMM_STAMPS
 	if (a.stagger == -1) m0 = n0 = 0;
@@ -723,9 +739,10 @@ bool vitk_gemm_bf16_256_ok(const vitk_gemm_desc& d) {
 	return true;
 }
 
-int vitk_gemm_bf16_256(const vitk_gemm_desc& d, hipStream_t st) {
+int vitk_gemm_bf16_256(const vitk_gemm_desc& d, hipStream_t st, bool* colsum_done) {
 	BigArgs a{};
 	a.g = make_gemm_dev(d);
+	a.a_colsum = d.a_colsum;
 	a.tiles_m = (int)vitk_cdiv(d.M, BM);
 	a.tiles_n = (int)vitk_cdiv(d.N, BN);
 	const int64_t tiles = (int64_t)a.tiles_m * a.tiles_n;
@@ -736,6 +753,8 @@ int vitk_gemm_bf16_256(const vitk_gemm_desc& d, hipStream_t st) {
 	if (d.out_dtype == VITK_F32 && d.epilogue == VITK_EPI_NONE && d.bias == nullptr && d.tokens_per_image == 0 && tiles <= 128 && ktiles >= 16) {
 		int64_t s = std::min<int64_t>(256 / tiles, ktiles / 8);
 		a.splits = (int)std::max<int64_t>(1, std::min<int64_t>(s, 64));
+		static const char* force = std::getenv("VITK_SPLITK");  // tuning / diagnosis
+		if (force != nullptr) a.splits = std::max(1, atoi(force));
 	}
 	const int64_t kt_per = vitk_cdiv(ktiles, a.splits);
 	a.k_per_split = (int)(kt_per * BK);
@@ -752,5 +771,8 @@ int vitk_gemm_bf16_256(const vitk_gemm_desc& d, hipStream_t st) {
 		hipError_t e = hipMemset2DAsync(d.C, (size_t)d.ldc * sizeof(float), 0, (size_t)d.N * sizeof(float), (size_t)d.M, st);
 		if (e != hipSuccess) return VITK_ERR_HIP - (int)e;
 	}
-	return launch_variant(a, d, dim3((unsigned)(tiles * a.splits)), st);
+	const int rc = launch_variant(a, d, dim3((unsigned)(tiles * a.splits)), st);
+	// only the float32-output kernel with MN-major A (weight gradients) carries the column sums
+	if (rc == VITK_OK && d.a_colsum != nullptr && d.a_layout == VITK_MN_MAJOR && d.b_layout == VITK_MN_MAJOR && d.out_dtype == VITK_F32) *colsum_done = true;
+	return rc;
 }

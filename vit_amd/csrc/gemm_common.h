@@ -128,7 +128,8 @@ __device__ __forceinline__ void epi_store4(const GemmDev& g, int64_t m, int64_t 
 }
 
 int vitk_gemm_generic(const vitk_gemm_desc& d, hipStream_t st);
-int vitk_gemm_bf16(const vitk_gemm_desc& d, hipStream_t st);  // returns VITK_ERR_UNSUPPORTED if the shape does not qualify
+// *colsum_done is set when the kernel that ran also accumulated d.a_colsum
+int vitk_gemm_bf16(const vitk_gemm_desc& d, hipStream_t st, bool* colsum_done);
 bool vitk_gemm_bf16_ok(const vitk_gemm_desc& d);
 bool vitk_gemm_bf16_256_ok(const vitk_gemm_desc& d);  // large-tile LDS-DMA kernel (needs K % 64 == 0, M, N >= 256)
-int vitk_gemm_bf16_256(const vitk_gemm_desc& d, hipStream_t st);
+int vitk_gemm_bf16_256(const vitk_gemm_desc& d, hipStream_t st, bool* colsum_done);

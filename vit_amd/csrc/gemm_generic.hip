@@ -114,9 +114,18 @@ extern "C" int vitk_gemm(const vitk_gemm_desc* desc, void* stream) {
 	VITK_REQUIRE(d.in_dtype == VITK_F32 || d.in_dtype == VITK_BF16, VITK_ERR_DTYPE);
 	VITK_REQUIRE(d.out_dtype == VITK_F32 || d.out_dtype == VITK_BF16, VITK_ERR_DTYPE);
 	VITK_REQUIRE(!(d.in_dtype == VITK_F32 && d.out_dtype == VITK_BF16), VITK_ERR_DTYPE);
+	if (d.a_colsum != nullptr) VITK_REQUIRE(d.a_layout == VITK_MN_MAJOR && d.patch_grid == 0, VITK_ERR_UNSUPPORTED);
 	hipStream_t st = (hipStream_t)stream;
-	if (d.in_dtype == VITK_BF16 && vitk_gemm_bf16_ok(d)) return vitk_gemm_bf16(d, st);
-	return vitk_gemm_generic(d, st);
+	if (d.in_dtype == VITK_BF16 && vitk_gemm_bf16_ok(d)) {
+		bool colsum_done = false;
+		const int rc = vitk_gemm_bf16(d, st, &colsum_done);
+		if (rc != VITK_OK || d.a_colsum == nullptr || colsum_done) return rc;
+	} else {
+		const int rc = vitk_gemm_generic(d, st);
+		if (rc != VITK_OK || d.a_colsum == nullptr) return rc;
+	}
+	// the kernel that ran does not fuse the column sums of A: A is [K rows][M columns] here
+	return vitk_colsum(d.A, d.a_colsum, d.K, d.M, d.lda, 1, d.in_dtype, stream);
 }
 
 extern "C" int vitk_gemm_uses_bf16_mfma(const vitk_gemm_desc* desc) {

@@ -135,7 +135,7 @@ GEMM_PROFILE = None  # set to a list to collect (kernel label, flops, start even
 
 
 def gemm(A, B, C, M, N, K, lda, ldb, ldc, a_layout=L.K_MAJOR, b_layout=L.K_MAJOR, bias=None, epilogue=L.EPI_NONE, act=L.ACT_NONE,
-		aux=None, ld_aux=0, out2=None, ld_out2=0, gamma=None, accumulate=False, patch=None, tokens_per_image=0, pos=None):
+		aux=None, ld_aux=0, out2=None, ld_out2=0, gamma=None, accumulate=False, patch=None, tokens_per_image=0, pos=None, a_colsum=None):
 	"""C[M,N] (+)= epilogue(sum_k A(m,k) B(n,k)); see include/vitk.h for the operand layouts."""
 	L.require_gpu(A, B, C)
 	d = L.GemmDesc()
@@ -152,6 +152,8 @@ def gemm(A, B, C, M, N, K, lda, ldb, ldc, a_layout=L.K_MAJOR, b_layout=L.K_MAJOR
 	d.bias, d.gamma, d.pos = L.ptr(bias), L.ptr(gamma), L.ptr(pos)
 	d.aux, d.ld_aux = L.ptr(aux), ld_aux
 	d.out2, d.ld_out2 = L.ptr(out2), ld_out2
+	d.a_colsum = L.ptr(a_colsum)
+	assert a_colsum is None or (a_colsum.dtype == torch.float32 and a_colsum.is_contiguous() and a_colsum.numel() == M)
 	for t in (bias, gamma, pos):
 		assert t is None or (t.dtype == torch.float32 and t.is_contiguous())
 	assert aux is None or aux.dtype == A.dtype
@@ -211,14 +213,17 @@ def linear_dgrad(dy, w, act=L.ACT_NONE, pre=None, out=None):
 	return dx
 
 
-def linear_wgrad(dy, x):
-	"""dw[N, K] = dy.T @ x in float32."""
+def linear_wgrad(dy, x, bias_grad=False):
+	"""dw[N, K] = dy.T @ x in float32.  With bias_grad also db[N] = column sums of dy, formed by the same kernel from
+	the dy tiles it stages anyway (or by a column-sum kernel after it, where the GEMM path that runs does not fuse
+	it): returns (dw, db)."""
 	M, N = dy.shape
 	K = x.shape[1]
 	assert x.shape[0] == M and dy.stride(1) == 1 and x.stride(1) == 1
 	dw = torch.empty((N, K), dtype=torch.float32, device=dy.device)
-	gemm(dy, x, dw, N, K, M, dy.stride(0), x.stride(0), K, a_layout=L.MN_MAJOR, b_layout=L.MN_MAJOR)
-	return dw
+	db = torch.zeros(N, dtype=torch.float32, device=dy.device) if bias_grad else None
+	gemm(dy, x, dw, N, K, M, dy.stride(0), x.stride(0), K, a_layout=L.MN_MAJOR, b_layout=L.MN_MAJOR, a_colsum=db)
+	return (dw, db) if bias_grad else dw
 
 
 def colsum(x):
@@ -397,15 +402,13 @@ def _ffn_forward(x2, w1, b1, w2, b2, act, gated, residual=None, gamma=None):
 
 def _ffn_backward(dy2, x2, u, a, w1, w2, act, gated, need_dx=True):
 	"""Returns (dx, dw1, db1, dw2, db2) with float32 parameter gradients."""
-	dw2 = linear_wgrad(dy2, a)
-	db2 = colsum(dy2)
+	dw2, db2 = linear_wgrad(dy2, a, bias_grad=True)
 	if gated:
 		da = linear_dgrad(dy2, w2)
 		du = gated_act_bwd(da, u, w2.shape[1], act)
 	else:
 		du = linear_dgrad(dy2, w2, act=act, pre=u)
-	dw1 = linear_wgrad(du, x2)
-	db1 = colsum(du)
+	dw1, db1 = linear_wgrad(du, x2, bias_grad=True)
 	dx = linear_dgrad(du, w1) if need_dx else None
 	return dx, dw1, db1, dw2, db2
 
@@ -448,8 +451,7 @@ def _mha_backward(dy2, x2, qkv, o, lse, wqkv, wo, B, S, n_head, need_dx=True):
 	"""Returns (dx, dwqkv, dwo, dbo)."""
 	d = x2.shape[1]
 	dh = d // n_head
-	dwo = linear_wgrad(dy2, o)
-	dbo = colsum(dy2)
+	dwo, dbo = linear_wgrad(dy2, o, bias_grad=True)
 	do = linear_dgrad(dy2, wo)
 	dqkv = torch.empty_like(qkv)
 	attention_bwd(do, qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], o, lse, dqkv[:, :d], dqkv[:, d:2 * d], dqkv[:, 2 * d:], B, n_head, S, S, dh)
@@ -582,8 +584,7 @@ class PatchEmbedFn(torch.autograd.Function):
 		L.check(lib.vitk_drop_cls_rows(L.ptr(dx), L.ptr(dtok), Bn, P2 + 1, d, dtc, L.stream()))
 		patches = torch.empty((Bn * P2, K), dtype=dt, device=dx.device)
 		L.check(lib.vitk_patchify(L.ptr(img), L.ptr(patches), Bn, C, H, n_patch, dtc, L.stream()))
-		dw = linear_wgrad(dtok, patches)
-		db = colsum(dtok)
+		dw, db = linear_wgrad(dtok, patches, bias_grad=True)
 		dimg = None
 		if ctx.needs_input_grad[0]:
 			dpatch = linear_dgrad(dtok, weight_as(w, dt))
@@ -617,8 +618,7 @@ class ClsHeadFn(torch.autograd.Function):
 		Bn, S, d = xc.shape
 		dy2 = cast(dy, dt)
 		rows0 = xc.reshape(Bn * S, d)[::S]
-		dw = linear_wgrad(dy2, rows0)
-		db = colsum(dy2)
+		dw, db = linear_wgrad(dy2, rows0, bias_grad=True)
 		dx = None
 		if ctx.needs_input_grad[0]:
 			dx = torch.zeros((Bn, S, d), dtype=dt, device=dy.device)
@@ -888,15 +888,15 @@ class ConvAttentionFn(torch.autograd.Function):
 		H, W, n_head, ks, stride, pad = cfg
 		dh = C // n_head
 		dy2 = _flat(cast(dy, dt))
-		dwo, dbo = linear_wgrad(dy2, o), colsum(dy2)
+		dwo, dbo = linear_wgrad(dy2, o, bias_grad=True)
 		do = linear_dgrad(dy2, weight_as(wo, dt))
 		dq, dk1, dv1 = torch.empty_like(q), torch.empty_like(k1), torch.empty_like(v1)
 		attention_bwd(do, q, k1, v1, o, lse, dq, dk1, dv1, Bn, n_head, S, Skv, dh)
 		dk0, dck = dwconv_bwd(dk1, k0, weight_as(ck, dt), Bn, H, W, C, ks, stride, pad)
 		dv0, dcv = dwconv_bwd(dv1, v0, weight_as(cv, dt), Bn, H, W, C, ks, stride, pad)
-		dwq, dbq = linear_wgrad(dq, x2), colsum(dq)
-		dwk, dbk = linear_wgrad(dk0, x2), colsum(dk0)
-		dwv, dbv = linear_wgrad(dv0, x2), colsum(dv0)
+		dwq, dbq = linear_wgrad(dq, x2, bias_grad=True)
+		dwk, dbk = linear_wgrad(dk0, x2, bias_grad=True)
+		dwv, dbv = linear_wgrad(dv0, x2, bias_grad=True)
 		dx = None
 		if ctx.needs_input_grad[0]:
 			# dx = dq Wq + dk0 Wk + dv0 Wv: the second and third GEMM add onto the first through the residual epilogue (C aliases aux)
