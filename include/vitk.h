@@ -105,9 +105,17 @@ typedef struct vitk_gemm_desc {
 	float* a_colsum;           /* [M] or null; MN-major A only: a_colsum[m] += sum_k A(m,k), i.e. the bias gradient
 	                              (column sums of dy) that autograd's addmm backward forms next to dW = dy^T x.
 	                              ACCUMULATED into: the caller zeroes it. */
+	void* workspace;           /* optional device scratch the call may use (it allocates nothing itself): with at
+	                              least vitk_gemm_workspace_bytes() the K-split weight-gradient GEMM writes its partial
+	                              tiles there and sums them in a second kernel (deterministic), instead of float
+	                              atomics into C.  Contents are undefined afterwards; calls that share it must be
+	                              ordered on one stream. */
+	int64_t workspace_bytes;
 } vitk_gemm_desc;
 
 int vitk_gemm(const vitk_gemm_desc* desc, void* stream);
+/* Size of `workspace` that is enough for any problem on this device (a fixed number of 256x256 float32 tiles). */
+int64_t vitk_gemm_workspace_bytes(void);
 /* 1 if vitk_gemm would run this problem on the bf16 MFMA kernel, 0 if on the generic float32-MFMA kernel. */
 int vitk_gemm_uses_bf16_mfma(const vitk_gemm_desc* desc);
 

@@ -150,6 +150,14 @@ def test_wgrad_with_bias_grad(gpu, dtype, M, N, K):
 	assert relerr(dw, dyr.t() @ xr) < tol
 	assert relerr(db, dyr.sum(0)) < tol
 	assert relerr(ops.linear_wgrad(dy, x), dyr.t() @ xr) < tol  # and without the bias gradient
+	# a caller without scratch memory: K slices are summed with float atomics into C; also accumulation into C
+	import vit_amd._lib as L
+	c = torch.full((N, K), 1.0, dtype=torch.float32, device=gpu)
+	ops.gemm(dy, x, c, N, K, M, N, K, K, a_layout=L.MN_MAJOR, b_layout=L.MN_MAJOR, workspace=False)
+	assert relerr(c, dyr.t() @ xr) < tol
+	ops.gemm(dy, x, c, N, K, M, N, K, K, a_layout=L.MN_MAJOR, b_layout=L.MN_MAJOR, accumulate=True, workspace=False)
+	ops.gemm(dy, x, c, N, K, M, N, K, K, a_layout=L.MN_MAJOR, b_layout=L.MN_MAJOR, accumulate=True)
+	assert relerr(c, 3.0 * (dyr.t() @ xr)) < tol
 
 
 @pytest.mark.parametrize("dtype", DTYPES)

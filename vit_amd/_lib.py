@@ -35,6 +35,7 @@ class GemmDesc(ctypes.Structure):
 		("aux", c_void_p), ("ld_aux", c_int64),
 		("out2", c_void_p), ("ld_out2", c_int64),
 		("a_colsum", c_void_p),
+		("workspace", c_void_p), ("workspace_bytes", c_int64),
 	]
 
 
@@ -46,6 +47,7 @@ SIGNATURES = {
 	"vitk_version": [],
 	"vitk_gemm": [POINTER(GemmDesc), P],
 	"vitk_gemm_uses_bf16_mfma": [POINTER(GemmDesc)],
+	"vitk_gemm_workspace_bytes": [],
 	"vitk_layernorm_fwd": [P, P, P, P, P, P, P, P, I64, I64, FL, I, P],
 	"vitk_layernorm_bwd": [P, P, P, P, P, P, P, P, P, I64, I64, I, P],
 	"vitk_rmsnorm_fwd": [P, P, P, P, P, P, I64, I64, FL, I, I, P],
@@ -78,7 +80,7 @@ SIGNATURES = {
 	"vitk_batchnorm_fwd": [P, P, P, P, P, P, P, P, I64, I64, FL, FL, I, I, P],
 	"vitk_batchnorm_bwd": [P, P, P, P, P, P, P, P, I64, I64, I, I, P],
 }
-_RESTYPES = {"vitk_strerror": c_char_p}
+_RESTYPES = {"vitk_strerror": c_char_p, "vitk_gemm_workspace_bytes": c_int64}
 
 _lib = None
 

@@ -165,6 +165,7 @@ struct BigArgs {
 	int tiles_m, tiles_n, splits, k_per_split;
 	int vec4, vec8;  // epilogue operands / outputs may be accessed 4-wide (8 / 16 bytes) resp. 8-wide (16 bytes bf16)
 	float* a_colsum;  // MN-major A: sum over k of A(m, k) is added here (bias gradient), or null
+	float* partials;  // K-split partial tiles [split][tile][wave][i][j][lane][4] (accumulator order), or null: float atomics into C
 #ifdef VITK_GEMM_STAMPS
 	long long* stamps;  // diagnostic builds only: [workgroup][round][8] timestamps of the persistent kernel
 	int stagger;        // diagnostic builds only: start delay step in 10 ns ticks
@@ -370,6 +371,16 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_256_kernel(BigArgs a) {
 		}
 		STAMP(4);
 	} else {
+		if (a.splits > 1 && a.partials != nullptr) {
+			// K-split partial tile: straight from the accumulators in their own order, every wave-instruction one
+			// contiguous KiB; split_reduce_kernel adds the slices up and undoes the order
+			float* dst = a.partials + ((int64_t)split * ntile + (int64_t)tm * a.tiles_n + tn) * (BM * BN) + (int64_t)wave * (32 * 256) + lane * 4;
+#pragma unroll
+			for (int i = 0; i < 8; ++i)
+#pragma unroll
+				for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(dst + (i * 4 + j) * 256) = acc[i][j];
+			return;
+		}
 		// float32 output (weight gradients, split-K partial sums): through a float LDS image, 128 rows at a time
 		float* ct = reinterpret_cast<float*>(smem);
 #pragma unroll
@@ -644,6 +655,33 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_256p_kernel(BigArgs a) 
 	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the last (unused) DMA must not outlive the workgroup's LDS
 }
 
+// C (+)= sum over the K slices of the partial tiles written above.  One thread per accumulator quad (4 consecutive
+// columns of one row): 16-byte loads at unit stride per slice, one 16-byte store.
+__global__ __launch_bounds__(256) void split_reduce_kernel(const float* __restrict__ partials, float* __restrict__ C, int64_t M, int64_t N, int64_t ldc, int tiles_n,
+	int ntile, int splits, int accumulate, int vec4) {
+	const int tile = blockIdx.y;
+	const int q = blockIdx.x * 256 + threadIdx.x;  // quad index inside the tile: ((wave * 8 + i) * 4 + j) * 64 + lane
+	const int lane = q & 63, j = (q >> 6) & 3, i = (q >> 8) & 7, wave = q >> 11;
+	const int64_t m = (int64_t)(tile / tiles_n) * BM + (wave >> 2) * 128 + 16 * i + (lane & 15);
+	const int64_t n = (int64_t)(tile % tiles_n) * BN + (wave & 3) * 64 + 16 * j + 4 * (lane >> 4);
+	if (m >= M || n >= N) return;
+	const float* src = partials + (int64_t)tile * (BM * BN) + (int64_t)q * 4;
+	f32x4 v = *reinterpret_cast<const f32x4*>(src);
+	for (int s = 1; s < splits; ++s) {
+		const f32x4 u = *reinterpret_cast<const f32x4*>(src + (int64_t)s * ntile * (BM * BN));
+		v += u;
+	}
+	float* c = C + m * ldc + n;
+	if (vec4 && n + 3 < N) {
+		if (accumulate) v += *reinterpret_cast<const f32x4*>(c);
+		*reinterpret_cast<f32x4*>(c) = v;
+	} else {
+#pragma unroll
+		for (int r = 0; r < 4; ++r)
+			if (n + r < N) c[r] = accumulate ? c[r] + v[r] : v[r];
+	}
+}
+
 template <int AL, int BL, typename TOUT, int EPI, int ACT>
 int launch1(const BigArgs& a, dim3 grid, hipStream_t st) {
 	static bool attr = false;
@@ -767,12 +805,24 @@ int vitk_gemm_bf16_256(const vitk_gemm_desc& d, hipStream_t st, bool* colsum_don
 	a.stamps = g_stamps;
 	a.stagger = g_stagger;
 #endif
-	if (a.splits > 1 && !d.accumulate) {
+	const int64_t need = (int64_t)a.splits * tiles * BM * BN * (int64_t)sizeof(float);
+	if (a.splits > 1 && d.workspace != nullptr && d.workspace_bytes >= need && vitk_aligned(d.workspace, 16)) a.partials = reinterpret_cast<float*>(d.workspace);
+	if (a.splits > 1 && a.partials == nullptr && !d.accumulate) {
 		hipError_t e = hipMemset2DAsync(d.C, (size_t)d.ldc * sizeof(float), 0, (size_t)d.N * sizeof(float), (size_t)d.M, st);
 		if (e != hipSuccess) return VITK_ERR_HIP - (int)e;
 	}
-	const int rc = launch_variant(a, d, dim3((unsigned)(tiles * a.splits)), st);
+	int rc = launch_variant(a, d, dim3((unsigned)(tiles * a.splits)), st);
+	if (rc == VITK_OK && a.partials != nullptr) {
+		hipLaunchKernelGGL(split_reduce_kernel, dim3(BM * BN / 4 / 256, (unsigned)tiles), dim3(256), 0, st, a.partials, reinterpret_cast<float*>(d.C), d.M, d.N, d.ldc, a.tiles_n,
+			(int)tiles, a.splits, d.accumulate, a.vec4);
+		VITK_CHECK_LAUNCH();
+	}
 	// only the float32-output kernel with MN-major A (weight gradients) carries the column sums
 	if (rc == VITK_OK && d.a_colsum != nullptr && d.a_layout == VITK_MN_MAJOR && d.b_layout == VITK_MN_MAJOR && d.out_dtype == VITK_F32) *colsum_done = true;
 	return rc;
+}
+
+// Split-K launches at most one workgroup per CU (plus rounding), each with one 256x256 float32 partial tile.
+extern "C" int64_t vitk_gemm_workspace_bytes(void) {
+	return (int64_t)(persistent_blocks() + 64) * BM * BN * (int64_t)sizeof(float);
 }

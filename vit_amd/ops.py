@@ -134,8 +134,19 @@ DGRAD_TRANSPOSED_WEIGHTS = True  # see linear_dgrad
 GEMM_PROFILE = None  # set to a list to collect (kernel label, flops, start event, end event) per launch
 
 
+_workspaces = {}  # device index -> uint8 scratch tensor handed to vitk_gemm (K-split partial tiles)
+
+
+def gemm_workspace(device):
+	ws = _workspaces.get(device.index)
+	if ws is None:
+		ws = torch.empty(int(L.load().vitk_gemm_workspace_bytes()), dtype=torch.uint8, device=device)
+		_workspaces[device.index] = ws
+	return ws
+
+
 def gemm(A, B, C, M, N, K, lda, ldb, ldc, a_layout=L.K_MAJOR, b_layout=L.K_MAJOR, bias=None, epilogue=L.EPI_NONE, act=L.ACT_NONE,
-		aux=None, ld_aux=0, out2=None, ld_out2=0, gamma=None, accumulate=False, patch=None, tokens_per_image=0, pos=None, a_colsum=None):
+		aux=None, ld_aux=0, out2=None, ld_out2=0, gamma=None, accumulate=False, patch=None, tokens_per_image=0, pos=None, a_colsum=None, workspace=True):
 	"""C[M,N] (+)= epilogue(sum_k A(m,k) B(n,k)); see include/vitk.h for the operand layouts."""
 	L.require_gpu(A, B, C)
 	d = L.GemmDesc()
@@ -153,6 +164,9 @@ def gemm(A, B, C, M, N, K, lda, ldb, ldc, a_layout=L.K_MAJOR, b_layout=L.K_MAJOR
 	d.aux, d.ld_aux = L.ptr(aux), ld_aux
 	d.out2, d.ld_out2 = L.ptr(out2), ld_out2
 	d.a_colsum = L.ptr(a_colsum)
+	if workspace and a_layout == L.MN_MAJOR and C.dtype == torch.float32:  # weight gradients: the only form that splits K
+		ws = gemm_workspace(C.device)
+		d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
 	assert a_colsum is None or (a_colsum.dtype == torch.float32 and a_colsum.is_contiguous() and a_colsum.numel() == M)
 	for t in (bias, gamma, pos):
 		assert t is None or (t.dtype == torch.float32 and t.is_contiguous())
