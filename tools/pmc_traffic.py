@@ -1,0 +1,51 @@
+"""HBM traffic per launch of the GEMM kernels from two rocprofv3 PMC passes over bench.py
+(`--pmc FETCH_SIZE` and `--pmc WRITE_SIZE`, separate runs, csv output).
+
+FETCH_SIZE / WRITE_SIZE are in KiB at the L2's memory-side interface.  On gfx950 FETCH_SIZE tallies the 128-byte
+requests of wide (16 B per lane) streaming reads at 64 bytes, so it is doubled; WRITE_SIZE is exact for 16-byte-per-lane
+stores.  Writes profiles/<out>.json: {label: {"launches", "fetch_bytes", "write_bytes", "traffic_bytes"}} per launch.
+
+usage: python tools/pmc_traffic.py fetch_counter_collection.csv write_counter_collection.csv out.json
+"""
+import collections
+import csv
+import json
+import re
+import sys
+
+
+def label_of(kernel_name):
+	"""bench.py's GEMM label (operand layouts) of a kernel instantiation, or None."""
+	m = re.search(r"gemm_bf16(?:_256p?)?_kernel<(\d), (\d)", kernel_name) or re.search(r"gemm_bf16(?:_256p?)?_kernelILi(\d)ELi(\d)E", kernel_name)
+	if m:
+		return f"gemm_bf16_mfma<A{m.group(1)},B{m.group(2)}>"
+	return None
+
+
+def per_label(path, counter):
+	tot, cnt = collections.defaultdict(float), collections.defaultdict(int)
+	for r in csv.DictReader(open(path)):
+		if r["Counter_Name"] != counter:
+			continue
+		lab = label_of(r["Kernel_Name"])
+		if lab is None:
+			continue
+		tot[lab] += float(r["Counter_Value"])
+		cnt[lab] += 1
+	return tot, cnt
+
+
+def main():
+	fetch, fc = per_label(sys.argv[1], "FETCH_SIZE")
+	write, wc = per_label(sys.argv[2], "WRITE_SIZE")
+	out = {}
+	for lab in fetch:
+		f = 2.0 * 1024.0 * fetch[lab] / fc[lab]
+		w = 1024.0 * write.get(lab, 0.0) / max(wc.get(lab, 1), 1)
+		out[lab] = {"launches": fc[lab], "fetch_bytes": f, "write_bytes": w, "traffic_bytes": f + w}
+		print(f"{lab}: {fc[lab]} launches, fetch {f/1e6:.1f} MB (x2 corrected), write {w/1e6:.1f} MB per launch")
+	json.dump(out, open(sys.argv[3], "w"), indent=1, sort_keys=True)
+
+
+if __name__ == "__main__":
+	main()
