@@ -108,11 +108,13 @@ __global__ __launch_bounds__(1024) void attn_fwd_mfma_kernel(AttnArgs a) {
 			f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 			acc = mfma16(row_frag(Ks, 16 * t, 0, lane), qf0, acc);
 			acc = mfma16(row_frag(Ks, 16 * t, 1, lane), qf1, acc);
+			if (16 * t + 16 > a.Skv) {  // wave-uniform: only the tile(s) that reach past the last key pay for the mask
 #pragma unroll
-			for (int r = 0; r < 4; ++r) {
-				if (16 * t + 4 * g + r >= a.Skv) acc[r] = -INFINITY;
-				m = fmaxf(m, acc[r]);
+				for (int r = 0; r < 4; ++r)
+					if (16 * t + 4 * g + r >= a.Skv) acc[r] = -INFINITY;
 			}
+#pragma unroll
+			for (int r = 0; r < 4; ++r) m = fmaxf(m, acc[r]);
 			st[t] = acc;
 			__builtin_amdgcn_sched_barrier(0);  // keep the unrolled iterations in order: hoisting all LDS reads spills
 		}
@@ -202,9 +204,13 @@ __global__ __launch_bounds__(1024) void attn_bwd_dq_mfma_kernel(AttnArgs a) {
 				dp = mfma16(row_frag(Vs, 16 * t, 1, lane), gf1, dp);
 #pragma unroll
 				for (int r = 0; r < 4; ++r) {
-					float p = __builtin_amdgcn_exp2f(s[r] * c - lse2);
-					if (16 * t + 4 * g + r >= a.Skv) p = 0.f;
+					const float p = __builtin_amdgcn_exp2f(s[r] * c - lse2);
 					ds[hf][r] = p * (dp[r] - delta) * a.scale;
+				}
+				if (16 * t + 16 > a.Skv) {  // wave-uniform: padded keys contribute nothing
+#pragma unroll
+					for (int r = 0; r < 4; ++r)
+						if (16 * t + 4 * g + r >= a.Skv) ds[hf][r] = 0.f;
 				}
 			}
 			const bf16x8 dsf = pack8(ds[0], ds[1]);
