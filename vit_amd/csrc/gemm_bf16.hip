@@ -291,6 +291,10 @@ int vitk_gemm_bf16(const vitk_gemm_desc& d, hipStream_t st, bool* colsum_done) {
 		const int rc = vitk_gemm_bf16_256(d, st, colsum_done);
 		if (rc != VITK_ERR_UNSUPPORTED) return rc;
 	}
+	return vitk_gemm_bf16_128(d, st);
+}
+
+int vitk_gemm_bf16_128(const vitk_gemm_desc& d, hipStream_t st) {
 	BfArgs a{};
 	a.g = make_gemm_dev(d);
 	a.tiles_m = (int)vitk_cdiv(d.M, BM);

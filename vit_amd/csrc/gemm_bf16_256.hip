@@ -777,7 +777,45 @@ bool vitk_gemm_bf16_256_ok(const vitk_gemm_desc& d) {
 	return true;
 }
 
+// A persistent launch whose last round of tiles would fill only part of the chip (N = 768 at 197 row tiles: 591 tiles =
+// 2.31 rounds of 256) is cut along M: the rows that make whole rounds stay on the persistent kernel, the remaining rows
+// go to the 128x128 kernel, whose four times smaller tiles spread that remainder over all CUs (measured on the
+// ViT-B/16 shapes: +2..5 % for K >= 2304, where the per-tile work is long; -3 % at K = 768, so short-K problems are
+// left alone).
+static int split_off_partial_round(const vitk_gemm_desc& d, hipStream_t st, bool* handled) {
+	*handled = false;
+	static const bool off = std::getenv("VITK_NO_TAIL_SPLIT") != nullptr;
+	if (off || d.out_dtype != VITK_BF16 || d.a_layout != VITK_K_MAJOR || d.accumulate || d.K < 1536) return VITK_OK;
+	const int64_t P = persistent_blocks();
+	const int64_t tiles_m = vitk_cdiv(d.M, BM), tiles_n = vitk_cdiv(d.N, BN);
+	const int64_t tiles = tiles_m * tiles_n;
+	if (tiles <= P) return VITK_OK;
+	const int64_t rounds = tiles / P, rem = tiles % P;
+	if (rem == 0 || rem * 10 > P * 6) return VITK_OK;
+	const int64_t tm1 = (rounds * P) / tiles_n;  // row tiles that fit into the whole rounds
+	const int64_t M1 = tm1 * BM;
+	if (tm1 <= 0 || M1 >= d.M) return VITK_OK;
+	vitk_gemm_desc d1 = d, d2 = d;
+	d1.M = M1;
+	d2.M = d.M - M1;
+	const size_t e = sizeof(bf16_t);
+	d2.A = reinterpret_cast<const char*>(d.A) + (size_t)M1 * d.lda * e;
+	d2.C = reinterpret_cast<char*>(d.C) + (size_t)M1 * d.ldc * e;
+	if (d.aux != nullptr) d2.aux = reinterpret_cast<const char*>(d.aux) + (size_t)M1 * d.ld_aux * e;
+	if (d.out2 != nullptr) d2.out2 = reinterpret_cast<char*>(d.out2) + (size_t)M1 * d.ld_out2 * e;
+	*handled = true;
+	bool unused = false;
+	int rc = vitk_gemm_bf16_256(d1, st, &unused);
+	if (rc != VITK_OK) return rc;
+	return vitk_gemm_bf16_128(d2, st);
+}
+
 int vitk_gemm_bf16_256(const vitk_gemm_desc& d, hipStream_t st, bool* colsum_done) {
+	{
+		bool handled = false;
+		const int rc = split_off_partial_round(d, st, &handled);
+		if (handled) return rc;
+	}
 	BigArgs a{};
 	a.g = make_gemm_dev(d);
 	a.a_colsum = d.a_colsum;
