@@ -82,6 +82,7 @@ def main():
 	ap.add_argument("--gpus", type=int, default=1)
 	ap.add_argument("--steps", type=int, default=10)
 	ap.add_argument("--warmup", type=int, default=3)
+	ap.add_argument("--graph", action="store_true", help="capture the training step into a HIP graph and replay it (single GPU)")
 	ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the config's)")
 	ap.add_argument("--config", default="vit_b16", choices=sorted(CONFIGS))
 	ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -125,9 +126,21 @@ def main():
 			dist.barrier()
 		torch.cuda.synchronize()
 
+	graphed = None
+	if args.graph:
+		# the whole step as one HIP graph launch (single process): for launch-bound configurations (ViT-Tiny)
+		assert world == 1, "--graph is single-GPU"
+
+		def loss_fn(xi, yi):
+			with torch.autocast("cuda", dtype=torch.bfloat16):
+				return ops.cross_entropy(model(xi), yi)
+		graphed = dp.GraphedStep(trainer, loss_fn, [x, y], warmup=max(args.warmup, 3))
+
+		def step():
+			return graphed(x, y)
 	for _ in range(args.warmup):
 		step()
-	if not args.no_kernel_timing and rank == 0:
+	if not args.no_kernel_timing and rank == 0 and graphed is None:
 		ops.GEMM_PROFILE = []
 	barrier()
 	t0 = time.perf_counter()
@@ -152,7 +165,7 @@ def main():
 			"dtype": "bf16", "data": "synthetic",
 			"config": {"workload": f"{args.config}: ViT d{c['d_model']}/h{c['n_head']}/L{c['n_block']}/ff{c['d_ff']} patch{c['chw'][1] // c['n_patch']} at {c['chw'][1]}x{c['chw'][2]}, "
 				f"{c['n_patch'] ** 2 + 1} tokens, fwd+CE+bwd+AdamW, fp32 master weights, bf16 activations", "global_batch": batch * world, "per_gpu_batch": batch,
-				"parallelism": f"dp{world}"},
+				"parallelism": f"dp{world}", "hip_graph": bool(args.graph)},
 			"train_gflop_per_image": round(flops_img / 1e9, 3),
 			"mfma_util_pct": round(100.0 * value * flops_img / (world * PEAK_BF16_TFLOPS * 1e12), 2),
 			"final_loss": round(final_loss, 4),

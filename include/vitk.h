@@ -220,6 +220,11 @@ int vitk_ce_kd_loss(const void* logits, const int64_t* labels, const void* teach
  */
 int vitk_adamw(float* p, const float* g, float* m, float* v, const uint8_t* wd_mask, void* p_bf16, int64_t n,
 	float lr, float beta1, float beta2, float eps, float weight_decay, int64_t step, float grad_scale, void* stream);
+/* The same step with the step count in DEVICE memory (`step_state[0]`, int64, starts at 0): the call increments it and
+ * derives the bias corrections from it on the device, so a launch captured into a HIP graph advances on every replay
+ * (the reference's eager loop, train.py:42-59, re-reads the optimizer's host-side step each iteration). */
+int vitk_adamw_device_step(float* p, const float* g, float* m, float* v, const uint8_t* wd_mask, void* p_bf16, int64_t n,
+	float lr, float beta1, float beta2, float eps, float weight_decay, int64_t* step_state, float grad_scale, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * CvT pieces.

@@ -222,3 +222,43 @@ def test_conv_embedding_golden(gpu, case, mode, dtype):
 		sd = m.state_dict()
 		for kk, v in sub(c, "sd_after").items():
 			assert relerr(sd[kk], v) < TOL[dtype], kk
+
+
+def test_graphed_training_step_matches_eager(gpu):
+	"""The captured-and-replayed training step (one HIP graph launch) follows the eager loop: same losses, same
+	parameters after the same number of optimizer steps on the same per-step batches."""
+	from vit_amd import dp, ops
+	c = dict(d_model=64, n_head=1, n_block=2, n_patch=4, d_ff=128, out_d=10, chw=(3, 16, 16), activation="gelu", norm="layernorm",
+		use_layer_scale=False, dropout=0.0)
+	gen = torch.Generator().manual_seed(5)
+	xs = [torch.randn(8, 3, 16, 16, generator=gen).to(gpu) for _ in range(7)]
+	ys = [torch.randint(0, 10, (8,), generator=gen).to(gpu) for _ in range(7)]
+
+	def run(graphed):
+		torch.manual_seed(0)
+		model = make_vit(c, gpu)
+		trainer = dp.Trainer(model, lr=1e-2, weight_decay=0.05)
+
+		def loss_fn(x, y):
+			with torch.autocast("cuda", dtype=torch.bfloat16):
+				return ops.cross_entropy(model(x), y)
+		losses = []
+		if graphed:
+			g = dp.GraphedStep(trainer, loss_fn, [xs[0], ys[0]], warmup=3)  # 3 eager steps on batch 0
+			for i in range(3, 7):
+				losses.append(float(g(xs[i], ys[i])))
+		else:
+			for i in [0, 0, 0, 3, 4, 5, 6]:
+				trainer.zero_grad()
+				loss = loss_fn(xs[i], ys[i])
+				loss.backward()
+				trainer.step()
+				losses.append(float(loss.detach()))
+			losses = losses[3:]
+		assert trainer.opt.step_count == 7 and int(trainer.opt.step_state[0]) == 7
+		return losses, trainer.flat.param.clone()
+
+	le, pe = run(False)
+	lg, pg = run(True)
+	assert max(abs(a - b) for a, b in zip(le, lg)) < 2e-2 * max(abs(a) for a in le)  # bf16 step, atomics order
+	assert relerr(pg, pe.cpu().double()) < 2e-2

@@ -318,9 +318,18 @@ __global__ __launch_bounds__(256) void ce_kd_kernel(const T* __restrict__ logits
 }
 
 // ---- fused AdamW -----------------------------------------------------------------------------------
+// step_state (nullable): [0] = step count as int64, kept in device memory so that a captured (graph-replayed) launch
+// sees a new step each time; the bias corrections are then computed here (in double, like the host path).
+__global__ void adamw_advance_kernel(int64_t* step_state) { step_state[0] += 1; }
+
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
 	const uint8_t* __restrict__ wd_mask, bf16_t* __restrict__ p16, int64_t n, float lr, float b1, float b2, float eps, float wd, float inv_bc1,
-	float inv_sqrt_bc2, float gscale) {
+	float inv_sqrt_bc2, float gscale, const int64_t* __restrict__ step_state) {
+	if (step_state != nullptr) {
+		const double st = (double)step_state[0];
+		inv_bc1 = (float)(1.0 / (1.0 - pow((double)b1, st)));
+		inv_sqrt_bc2 = (float)(1.0 / sqrt(1.0 - pow((double)b2, st)));
+	}
 	for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
 		const float gr = g[i] * gscale;
 		float pv = p[i];
@@ -578,7 +587,19 @@ extern "C" int vitk_adamw(float* p, const float* g, float* m, float* v, const ui
 	const double bc1 = 1.0 - pow((double)beta1, (double)step);
 	const double bc2 = 1.0 - pow((double)beta2, (double)step);
 	hipLaunchKernelGGL(adamw_kernel, dim3(vitk_stream_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, wd_mask, (bf16_t*)p_bf16, n, lr, beta1, beta2, eps,
-		weight_decay, (float)(1.0 / bc1), (float)(1.0 / sqrt(bc2)), grad_scale);
+		weight_decay, (float)(1.0 / bc1), (float)(1.0 / sqrt(bc2)), grad_scale, (const int64_t*)nullptr);
+	VITK_CHECK_LAUNCH();
+	return VITK_OK;
+}
+
+extern "C" int vitk_adamw_device_step(float* p, const float* g, float* m, float* v, const uint8_t* wd_mask, void* p_bf16, int64_t n, float lr, float beta1,
+	float beta2, float eps, float weight_decay, int64_t* step_state, float grad_scale, void* stream) {
+	VITK_REQUIRE(p && g && m && v && step_state, VITK_ERR_NULL);
+	VITK_REQUIRE(n > 0, VITK_ERR_SHAPE);
+	hipLaunchKernelGGL(adamw_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step_state);
+	VITK_CHECK_LAUNCH();
+	hipLaunchKernelGGL(adamw_kernel, dim3(vitk_stream_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, wd_mask, (bf16_t*)p_bf16, n, lr, beta1, beta2, eps,
+		weight_decay, 1.f, 1.f, grad_scale, (const int64_t*)step_state);
 	VITK_CHECK_LAUNCH();
 	return VITK_OK;
 }

@@ -128,6 +128,7 @@ class FlatAdamW:
 		self.m = torch.zeros_like(flat.param)
 		self.v = torch.zeros_like(flat.param)
 		self.step_count = 0
+		self.step_state = torch.zeros(2, dtype=torch.int64, device=dev)
 		mask = torch.ones(flat.numel, dtype=torch.uint8, device="cpu")
 		for n, p, o in zip(flat.names, flat.params, flat.offsets):
 			if decay_filter(n):
@@ -141,11 +142,18 @@ class FlatAdamW:
 				if p.dim() >= 2:
 					ops.register_shadow(p, self.shadow[o:o + p.numel()].view(p.shape))
 
+	def set_step(self, n):
+		"""Set the number of steps taken so far (resuming from a checkpoint)."""
+		self.step_count = int(n)
+		self.step_state.fill_(int(n))
+
 	def step(self, grad_scale=1.0):
+		# the step count that the bias corrections use lives in device memory (self.step_state) and is advanced by the
+		# launch itself, so the same launch can be replayed from a captured HIP graph; step_count mirrors it on the host
 		self.step_count += 1
 		f = self.flat
-		L.check(L.load().vitk_adamw(L.ptr(f.param), L.ptr(f.grad), L.ptr(self.m), L.ptr(self.v), L.ptr(self.wd_mask), L.ptr(self.shadow), f.numel,
-			self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay, self.step_count, grad_scale, L.stream()))
+		L.check(L.load().vitk_adamw_device_step(L.ptr(f.param), L.ptr(f.grad), L.ptr(self.m), L.ptr(self.v), L.ptr(self.wd_mask), L.ptr(self.shadow), f.numel,
+			self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay, L.ptr(self.step_state), grad_scale, L.stream()))
 		if self.shadow is None:
 			ops.invalidate_casts()  # the kernel writes the parameters without bumping their version counters
 		ops.weights_changed()  # cached transposed weight copies are stale now
@@ -170,3 +178,47 @@ class Trainer:
 	def step(self):
 		self.sync.finish()
 		self.opt.step(1.0 / self.sync.world)
+
+
+class GraphedStep:
+	"""One whole training step -- zero_grad, forward + loss (`loss_fn`), backward, optimizer -- captured once into a HIP
+	graph and replayed per call: one graph launch instead of ~10^3 kernel launches, which is what a small model
+	(ViT-Tiny on 32x32: ~1 ms of GPU work per step behind ~8 ms of launch overhead) is bound by.  The reference's loop
+	(train.py:42-59) is eager and synchronises twice per step; this is the launch-free form of the same step.
+
+	`loss_fn(*inputs)` must return the scalar loss and may only depend on its tensor arguments (their shapes and dtypes
+	are fixed at capture; new values are copied into the captured input buffers).  Single process only (the gradient
+	all-reduce hooks are not captured).  Counter-based dropout would replay the captured seed: use dropout 0 or
+	accept a fixed mask.  The returned loss tensor is overwritten by the next call."""
+
+	def __init__(self, trainer, loss_fn, example_inputs, warmup=3):
+		assert trainer.sync.world == 1, "graph capture of the step is single-process"
+		assert ops.GEMM_PROFILE is None, "no per-launch event timing inside a captured step"
+		self.trainer, self.loss_fn = trainer, loss_fn
+		self.inputs = [t.clone() for t in example_inputs]
+		side = torch.cuda.Stream()
+		side.wait_stream(torch.cuda.current_stream())
+		with torch.cuda.stream(side):  # warm-up off the default stream: lazy one-time setup must not happen during capture
+			for _ in range(warmup):
+				self._eager()
+		torch.cuda.current_stream().wait_stream(side)
+		self.graph = torch.cuda.CUDAGraph()
+		with torch.cuda.graph(self.graph):
+			self.loss = self._eager()
+		self.steps_in_capture = warmup + 1  # optimizer steps already taken (the capture itself executes nothing)
+		trainer.opt.step_count -= 1  # the captured step did not run; the device-side counter was not advanced either
+
+	def _eager(self):
+		self.trainer.zero_grad()
+		loss = self.loss_fn(*self.inputs)
+		loss.backward()
+		self.trainer.step()
+		return loss.detach()
+
+	def __call__(self, *inputs):
+		for dst, src in zip(self.inputs, inputs):
+			if dst.data_ptr() != src.data_ptr():
+				dst.copy_(src, non_blocking=True)
+		self.graph.replay()
+		self.trainer.opt.step_count += 1
+		return self.loss
