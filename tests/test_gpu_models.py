@@ -262,3 +262,38 @@ def test_graphed_training_step_matches_eager(gpu):
 	lg, pg = run(True)
 	assert max(abs(a - b) for a, b in zip(le, lg)) < 2e-2 * max(abs(a) for a in le)  # bf16 step, atomics order
 	assert relerr(pg, pe.cpu().double()) < 2e-2
+
+
+@pytest.mark.parametrize("cfg", ["ln_gelu", "rms_swiglu_ls"])
+def test_gradient_sinks_match_autograd(gpu, cfg):
+	"""With a Trainer the block backward adds parameter gradients straight into the flat gradient buffer (and autograd
+	sees None for them); the buffer must hold what plain autograd accumulation produces, also over two backward passes."""
+	from vit_amd import dp, ops
+	c = dict(d_model=64, n_head=1, n_block=2, n_patch=4, d_ff=128, out_d=10, chw=(3, 16, 16), dropout=0.0)
+	c.update(dict(activation="gelu", norm="layernorm", use_layer_scale=False) if cfg == "ln_gelu" else dict(activation="swiglu", norm="rmsnorm", use_layer_scale=True))
+	gen = torch.Generator().manual_seed(9)
+	x = torch.randn(8, 3, 16, 16, generator=gen).to(gpu)
+	y = torch.randint(0, 10, (8,), generator=gen).to(gpu)
+
+	def grads(with_trainer):
+		ops.clear_grad_sinks()
+		torch.manual_seed(0)
+		model = make_vit(c, gpu)
+		trainer = dp.Trainer(model) if with_trainer else None
+		arrivals = []
+		if with_trainer:
+			for i, p in enumerate(trainer.flat.params):  # count sink / hook arrivals like the data-parallel sync does
+				ops.register_grad_sink(p, trainer.flat.grad[trainer.flat.offsets[i]:trainer.flat.offsets[i] + p.numel()].view(p.shape), lambda _p, i=i: arrivals.append(i))
+			trainer.zero_grad()
+		for _ in range(2):
+			ops.cross_entropy(model(x), y).backward()
+		out = {n: p.grad.detach().clone() for n, p in model.named_parameters()}
+		ops.clear_grad_sinks()
+		return out, arrivals
+
+	ref, _ = grads(False)
+	got, arrivals = grads(True)
+	assert set(ref) == set(got)
+	for n in ref:
+		assert relerr(got[n], ref[n].cpu().double()) < 1e-4, n
+	assert len(arrivals) > 0 and max(arrivals.count(i) for i in set(arrivals)) == 2  # once per backward

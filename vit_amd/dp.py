@@ -82,9 +82,11 @@ class GradSync:
 		self.pending = [0] * len(flat.buckets)
 		self.works = []
 		self.launched = []
+		self.hooks = [None] * len(flat.params)
 		if self.world > 1:
 			for i, p in enumerate(flat.params):
-				p.register_post_accumulate_grad_hook(self._make_hook(i))
+				self.hooks[i] = self._make_hook(i)
+				p.register_post_accumulate_grad_hook(self.hooks[i])
 		self.reset()
 
 	def reset(self):
@@ -171,6 +173,10 @@ class Trainer:
 		self.flat = FlatModel(module, bucket_bytes)
 		self.sync = GradSync(self.flat)
 		self.opt = FlatAdamW(self.flat, lr, betas, eps, weight_decay)
+		# backward kernels that know about gradient sinks add straight into the flat gradient buffer (no temporary, no
+		# autograd accumulation kernel); they report through the same arrival hook as autograd's accumulation
+		for i, (p, o) in enumerate(zip(self.flat.params, self.flat.offsets)):
+			ops.register_grad_sink(p, self.flat.grad[o:o + p.numel()].view(p.shape), self.sync.hooks[i])
 
 	def zero_grad(self):
 		self.flat.zero_grad()

@@ -113,6 +113,44 @@ def weight_t(wc):
 	return out
 
 
+_grad_sinks = {}  # id(param) -> (weakref(param), float32 buffer of the parameter's shape, callback or None)
+
+
+def register_grad_sink(param, buffer, on_written=None):
+	"""Declare `buffer` (float32, the parameter's shape, contiguous; typically a slice of a flat gradient buffer that
+	param.grad is a view of) as the place where backward kernels ACCUMULATE the gradient of `param` directly: the
+	sink-aware backward functions then add into it (weight-gradient GEMM with accumulate, bias / norm gradients by the
+	kernels' own accumulation) and hand autograd `None` for that parameter, which saves the gradient temporary, its
+	zero-fill and autograd's `grad += temporary` kernel.  `on_written(param)` is called once per backward of a
+	function that wrote the sink (the data-parallel trainer counts these like post-accumulate-grad hooks).  The
+	owner zeroes the buffer between steps.  A parameter must not also receive a gradient through plain autograd in the
+	same backward if the callback counts arrivals."""
+	assert buffer.dtype == torch.float32 and buffer.shape == param.shape and buffer.is_contiguous()
+	pid = id(param)
+	_grad_sinks[pid] = (weakref.ref(param, lambda _r, pid=pid: _grad_sinks.pop(pid, None)), buffer, on_written)
+
+
+def clear_grad_sinks():
+	_grad_sinks.clear()
+
+
+def _sink(p):
+	"""(buffer, callback) if gradients of parameter `p` go to a registered sink, else None."""
+	if p is None:
+		return None
+	s = _grad_sinks.get(id(p))
+	if s is None or s[0]() is not p:
+		return None
+	return s[1], s[2]
+
+
+def _sink_done(p, sink):
+	"""Autograd's return value for a parameter whose gradient was accumulated into its sink."""
+	if sink[1] is not None:
+		sink[1](p)
+	return None
+
+
 def f32(t):
 	"""float32 view/copy of a small parameter vector (norm weights, biases, LayerScale)."""
 	if t is None:
@@ -227,16 +265,19 @@ def linear_dgrad(dy, w, act=L.ACT_NONE, pre=None, out=None):
 	return dx
 
 
-def linear_wgrad(dy, x, bias_grad=False):
+def linear_wgrad(dy, x, bias_grad=False, dw_out=None, db_out=None):
 	"""dw[N, K] = dy.T @ x in float32.  With bias_grad also db[N] = column sums of dy, formed by the same kernel from
 	the dy tiles it stages anyway (or by a column-sum kernel after it, where the GEMM path that runs does not fuse
-	it): returns (dw, db)."""
+	it): returns (dw, db).  dw_out / db_out: float32 buffers that the results are ADDED into instead (gradient
+	sinks); they are returned in place of fresh tensors."""
 	M, N = dy.shape
 	K = x.shape[1]
 	assert x.shape[0] == M and dy.stride(1) == 1 and x.stride(1) == 1
-	dw = torch.empty((N, K), dtype=torch.float32, device=dy.device)
-	db = torch.zeros(N, dtype=torch.float32, device=dy.device) if bias_grad else None
-	gemm(dy, x, dw, N, K, M, dy.stride(0), x.stride(0), K, a_layout=L.MN_MAJOR, b_layout=L.MN_MAJOR, a_colsum=db)
+	dw = dw_out if dw_out is not None else torch.empty((N, K), dtype=torch.float32, device=dy.device)
+	db = None
+	if bias_grad:
+		db = db_out if db_out is not None else torch.zeros(N, dtype=torch.float32, device=dy.device)
+	gemm(dy, x, dw, N, K, M, dy.stride(0), x.stride(0), K, a_layout=L.MN_MAJOR, b_layout=L.MN_MAJOR, a_colsum=db, accumulate=dw_out is not None)
 	return (dw, db) if bias_grad else dw
 
 
@@ -267,17 +308,23 @@ def norm_fwd(x, weight, bias, kind, eps, unit_offset=True, res=None):
 	return y, s, None, rstd
 
 
-def norm_bwd(dy, x, weight, mean, rstd, kind, unit_offset=True, dres=None):
-	"""Returns (dx, dweight_f32, dbias_f32_or_None); dres (same shape as x) is added into dx."""
+def norm_bwd(dy, x, weight, mean, rstd, kind, unit_offset=True, dres=None, dw_out=None, db_out=None):
+	"""Returns (dx, dweight_f32, dbias_f32_or_None); dres (same shape as x) is added into dx.  dw_out / db_out: float32
+	[d] buffers the kernel accumulates into instead of fresh zeroed ones (gradient sinks)."""
 	rows, d = x.shape
 	assert dy.is_contiguous() and x.is_contiguous() and (dres is None or dres.is_contiguous())
 	dx = torch.empty_like(x)
-	dwb = torch.zeros((2, d), dtype=torch.float32, device=x.device)  # one fill for both accumulators
-	dw = dwb[0]
+	need_b = kind == "layernorm"
+	if dw_out is not None and (db_out is not None or not need_b):
+		dw, dbuf = dw_out, db_out
+	else:
+		dwb = torch.zeros((2, d), dtype=torch.float32, device=x.device)  # one fill for both accumulators
+		dw = dw_out if dw_out is not None else dwb[0]
+		dbuf = db_out if db_out is not None else dwb[1]
 	lib = L.load()
 	dt = L.dtype_code(x.dtype)
 	if kind == "layernorm":
-		db = dwb[1]
+		db = dbuf
 		L.check(lib.vitk_layernorm_bwd(L.ptr(dy), L.ptr(x), L.ptr(weight), L.ptr(mean), L.ptr(rstd), L.ptr(dres), L.ptr(dx), L.ptr(dw), L.ptr(db), rows, d, dt, L.stream()))
 		return dx, dw, db
 	L.check(lib.vitk_rmsnorm_bwd(L.ptr(dy), L.ptr(x), L.ptr(weight), L.ptr(rstd), L.ptr(dres), L.ptr(dx), L.ptr(dw), rows, d, int(unit_offset), dt, L.stream()))
@@ -414,15 +461,16 @@ def _ffn_forward(x2, w1, b1, w2, b2, act, gated, residual=None, gamma=None):
 	return y, u, a
 
 
-def _ffn_backward(dy2, x2, u, a, w1, w2, act, gated, need_dx=True):
-	"""Returns (dx, dw1, db1, dw2, db2) with float32 parameter gradients."""
-	dw2, db2 = linear_wgrad(dy2, a, bias_grad=True)
+def _ffn_backward(dy2, x2, u, a, w1, w2, act, gated, need_dx=True, outs=(None, None, None, None)):
+	"""Returns (dx, dw1, db1, dw2, db2) with float32 parameter gradients.  outs = buffers to accumulate
+	(dw1, db1, dw2, db2) into (gradient sinks) or None each."""
+	dw2, db2 = linear_wgrad(dy2, a, bias_grad=True, dw_out=outs[2], db_out=outs[3])
 	if gated:
 		da = linear_dgrad(dy2, w2)
 		du = gated_act_bwd(da, u, w2.shape[1], act)
 	else:
 		du = linear_dgrad(dy2, w2, act=act, pre=u)
-	dw1, db1 = linear_wgrad(du, x2, bias_grad=True)
+	dw1, db1 = linear_wgrad(du, x2, bias_grad=True, dw_out=outs[0], db_out=outs[1])
 	dx = linear_dgrad(du, w1) if need_dx else None
 	return dx, dw1, db1, dw2, db2
 
@@ -461,15 +509,15 @@ def _mha_forward(x2, wqkv, wo, bo, B, S, n_head, residual=None, gamma=None):
 	return y, qkv, o, lse
 
 
-def _mha_backward(dy2, x2, qkv, o, lse, wqkv, wo, B, S, n_head, need_dx=True):
-	"""Returns (dx, dwqkv, dwo, dbo)."""
+def _mha_backward(dy2, x2, qkv, o, lse, wqkv, wo, B, S, n_head, need_dx=True, outs=(None, None, None)):
+	"""Returns (dx, dwqkv, dwo, dbo).  outs = buffers to accumulate (dwqkv, dwo, dbo) into (gradient sinks) or None."""
 	d = x2.shape[1]
 	dh = d // n_head
-	dwo, dbo = linear_wgrad(dy2, o, bias_grad=True)
+	dwo, dbo = linear_wgrad(dy2, o, bias_grad=True, dw_out=outs[1], db_out=outs[2])
 	do = linear_dgrad(dy2, wo)
 	dqkv = torch.empty_like(qkv)
 	attention_bwd(do, qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], o, lse, dqkv[:, :d], dqkv[:, d:2 * d], dqkv[:, 2 * d:], B, n_head, S, S, dh)
-	dwqkv = linear_wgrad(dqkv, x2)
+	dwqkv = linear_wgrad(dqkv, x2, dw_out=outs[0])
 	dx = linear_dgrad(dqkv, wqkv) if need_dx else None
 	return dx, dwqkv, dwo, dbo
 
@@ -545,20 +593,27 @@ class ViTBlockFn(torch.autograd.Function):
 			dbr2, dls2 = layerscale_bwd(dx2, br2, f32(ls2))
 		else:
 			dbr2, dls2 = dx2, None
-		dn2, dw1, db1, dw2, db2 = _ffn_backward(dbr2, n2, u, a, w1_c, w2_c, act, gated)
-		dx1, dn2w, dn2b = norm_bwd(dn2, x1, f32(n2w), mean2, rstd2, kind, unit_offset, dres=dx2)
+		# parameters with a registered gradient sink get their gradients accumulated in place by the kernels
+		sk = {n: _sink(t) for n, t in (("n1w", n1w), ("n1b", n1b), ("wqkv", wqkv), ("wo", wo), ("bo", bo), ("n2w", n2w), ("n2b", n2b), ("w1", w1), ("b1", b1),
+			("w2", w2), ("b2", b2))}
+		buf = {n: (v[0] if v is not None else None) for n, v in sk.items()}
+		dn2, dw1, db1, dw2, db2 = _ffn_backward(dbr2, n2, u, a, w1_c, w2_c, act, gated, outs=(buf["w1"], buf["b1"], buf["w2"], buf["b2"]))
+		dx1, dn2w, dn2b = norm_bwd(dn2, x1, f32(n2w), mean2, rstd2, kind, unit_offset, dres=dx2, dw_out=buf["n2w"], db_out=buf["n2b"])
 		# attention branch
 		if ls1 is not None:
 			dbr1, dls1 = layerscale_bwd(dx1, br1, f32(ls1))
 		else:
 			dbr1, dls1 = dx1, None
-		dn1, dwqkv, dwo, dbo = _mha_backward(dbr1, n1, qkv, o, lse, wqkv_c, wo_c, B, S, n_head)
-		dx0, dn1w, dn1b = norm_bwd(dn1, x0, f32(n1w), mean1, rstd1, kind, unit_offset, dres=dx1)
+		dn1, dwqkv, dwo, dbo = _mha_backward(dbr1, n1, qkv, o, lse, wqkv_c, wo_c, B, S, n_head, outs=(buf["wqkv"], buf["wo"], buf["bo"]))
+		dx0, dn1w, dn1b = norm_bwd(dn1, x0, f32(n1w), mean1, rstd1, kind, unit_offset, dres=dx1, dw_out=buf["n1w"], db_out=buf["n1b"])
 		dx0 = dx0.reshape(B, S, d)
 		if dx0.dtype != xdtype:
 			dx0 = cast(dx0, xdtype)
-		return (dx0, grad_as(dn1w, n1w), grad_as(dn1b, n1b), grad_as(dwqkv, wqkv), grad_as(dwo, wo), grad_as(dbo, bo), grad_as(dls1, ls1),
-			grad_as(dn2w, n2w), grad_as(dn2b, n2b), grad_as(dw1, w1), grad_as(db1, b1), grad_as(dw2, w2), grad_as(db2, b2), grad_as(dls2, ls2), None)
+
+		def out(name, g, p):
+			return _sink_done(p, sk[name]) if sk[name] is not None else grad_as(g, p)
+		return (dx0, out("n1w", dn1w, n1w), out("n1b", dn1b, n1b), out("wqkv", dwqkv, wqkv), out("wo", dwo, wo), out("bo", dbo, bo), grad_as(dls1, ls1),
+			out("n2w", dn2w, n2w), out("n2b", dn2b, n2b), out("w1", dw1, w1), out("b1", db1, b1), out("w2", dw2, w2), out("b2", db2, b2), grad_as(dls2, ls2), None)
 
 
 class PatchEmbedFn(torch.autograd.Function):
