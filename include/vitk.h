@@ -166,6 +166,15 @@ int vitk_cast(const void* src, void* dst, int64_t n, int src_dtype, int dst_dtyp
  * bf16 copy of a Linear weight so that the input-gradient GEMM of autograd (the dy @ W of nn.Linear's backward,
  * reached from layers/transformers.py:43-54 and layers/attention.py:36-59) reads both operands K-major. */
 int vitk_transpose(const void* x, void* y, int64_t rows, int64_t cols, int64_t ldx, int64_t ldy, int dtype, void* stream);
+/* All weight copies of a model transposed by ONE launch (after each optimizer step).  `items_dev`: device array of
+ * contiguous matrices; `tiles_dev`: device array of n_tiles x 4 int32 {item index, 64-row tile, 64-column tile, 0},
+ * one entry per 64x64 tile of every matrix (built once by the caller). */
+typedef struct vitk_transpose_item {
+	const void* src; /* [rows, cols] contiguous */
+	void* dst;       /* [cols, rows] contiguous */
+	int64_t rows, cols;
+} vitk_transpose_item;
+int vitk_transpose_batched(const vitk_transpose_item* items_dev, const int32_t* tiles_dev, int64_t n_tiles, int dtype, void* stream);
 /* out[n] (+)= sum_m x[m*ld + n]  — bias gradient of a Linear (autograd of addmm) */
 int vitk_colsum(const void* x, float* out, int64_t M, int64_t N, int64_t ld, int accumulate, int dtype, void* stream);
 /* Gated FFN (layers/transformers.py:48-50): u = [gate | up] with row stride ld_u, a = gate * act(up). */
@@ -220,8 +229,8 @@ int vitk_ce_kd_loss(const void* logits, const int64_t* labels, const void* teach
  */
 int vitk_adamw(float* p, const float* g, float* m, float* v, const uint8_t* wd_mask, void* p_bf16, int64_t n,
 	float lr, float beta1, float beta2, float eps, float weight_decay, int64_t step, float grad_scale, void* stream);
-/* The same step with the step count in DEVICE memory (`step_state[0]`, int64, starts at 0): the call increments it and
- * derives the bias corrections from it on the device, so a launch captured into a HIP graph advances on every replay
+/* The same step with the step count in DEVICE memory (`step_state`: two int64 words, [0] = count, starts at 0, [1] =
+ * scratch for the call): the call increments it and derives the bias corrections from it on the device, so a launch captured into a HIP graph advances on every replay
  * (the reference's eager loop, train.py:42-59, re-reads the optimizer's host-side step each iteration). */
 int vitk_adamw_device_step(float* p, const float* g, float* m, float* v, const uint8_t* wd_mask, void* p_bf16, int64_t n,
 	float lr, float beta1, float beta2, float eps, float weight_decay, int64_t* step_state, float grad_scale, void* stream);

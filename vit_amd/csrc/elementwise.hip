@@ -318,17 +318,23 @@ __global__ __launch_bounds__(256) void ce_kd_kernel(const T* __restrict__ logits
 }
 
 // ---- fused AdamW -----------------------------------------------------------------------------------
-// step_state (nullable): [0] = step count as int64, kept in device memory so that a captured (graph-replayed) launch
-// sees a new step each time; the bias corrections are then computed here (in double, like the host path).
-__global__ void adamw_advance_kernel(int64_t* step_state) { step_state[0] += 1; }
+// step_state (nullable): two int64 words in device memory, [0] = step count, [1] = the step's two bias-correction factors
+// as floats (computed in double, like the host path), so that a captured (graph-replayed) launch sees a new step each time.
+__global__ void adamw_advance_kernel(int64_t* step_state, float b1, float b2) {
+	const int64_t st = step_state[0] + 1;
+	step_state[0] = st;
+	float* corr = reinterpret_cast<float*>(step_state + 1);  // [1]: the two bias-correction factors of this step
+	corr[0] = (float)(1.0 / (1.0 - pow((double)b1, (double)st)));
+	corr[1] = (float)(1.0 / sqrt(1.0 - pow((double)b2, (double)st)));
+}
 
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
 	const uint8_t* __restrict__ wd_mask, bf16_t* __restrict__ p16, int64_t n, float lr, float b1, float b2, float eps, float wd, float inv_bc1,
 	float inv_sqrt_bc2, float gscale, const int64_t* __restrict__ step_state) {
 	if (step_state != nullptr) {
-		const double st = (double)step_state[0];
-		inv_bc1 = (float)(1.0 / (1.0 - pow((double)b1, st)));
-		inv_sqrt_bc2 = (float)(1.0 / sqrt(1.0 - pow((double)b2, st)));
+		const float* corr = reinterpret_cast<const float*>(step_state + 1);
+		inv_bc1 = corr[0];
+		inv_sqrt_bc2 = corr[1];
 	}
 	for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
 		const float gr = g[i] * gscale;
@@ -377,6 +383,40 @@ __global__ __launch_bounds__(256) void transpose_kernel(const T* __restrict__ x,
 		const int64_t c = c0 + i, r = r0 + tx;
 		if (r < rows && c < cols) y[c * ldy + r] = tile[tx][i];
 	}
+}
+
+// Many transposes in one launch: block b works on tile (tiles[b].y, tiles[b].z) of matrix tiles[b].x.
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_batched_kernel(const vitk_transpose_item* __restrict__ items, const int4* __restrict__ tiles) {
+	__shared__ T tile[64][65];
+	const int4 tb = tiles[blockIdx.x];
+	const vitk_transpose_item it = items[tb.x];
+	const T* __restrict__ x = reinterpret_cast<const T*>(it.src);
+	T* __restrict__ y = reinterpret_cast<T*>(it.dst);
+	const int64_t r0 = (int64_t)tb.y * 64, c0 = (int64_t)tb.z * 64;
+	const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+#pragma unroll 4
+	for (int i = ty; i < 64; i += 4) {
+		const int64_t r = r0 + i, c = c0 + tx;
+		if (r < it.rows && c < it.cols) tile[i][tx] = x[r * it.cols + c];
+	}
+	__syncthreads();
+#pragma unroll 4
+	for (int i = ty; i < 64; i += 4) {
+		const int64_t c = c0 + i, r = r0 + tx;
+		if (r < it.rows && c < it.cols) y[c * it.rows + r] = tile[tx][i];
+	}
+}
+
+extern "C" int vitk_transpose_batched(const vitk_transpose_item* items_dev, const int32_t* tiles_dev, int64_t n_tiles, int dtype, void* stream) {
+	VITK_REQUIRE(items_dev && tiles_dev, VITK_ERR_NULL);
+	VITK_REQUIRE(n_tiles >= 0 && n_tiles < (1ll << 31), VITK_ERR_SHAPE);
+	if (n_tiles == 0) return VITK_OK;
+	DISPATCH_T(dtype, {
+		hipLaunchKernelGGL((transpose_batched_kernel<T>), dim3((unsigned)n_tiles), dim3(256), 0, (hipStream_t)stream, items_dev, reinterpret_cast<const int4*>(tiles_dev));
+		VITK_CHECK_LAUNCH();
+		return VITK_OK;
+	});
 }
 
 extern "C" int vitk_transpose(const void* x, void* y, int64_t rows, int64_t cols, int64_t ldx, int64_t ldy, int dtype, void* stream) {
@@ -596,7 +636,7 @@ extern "C" int vitk_adamw_device_step(float* p, const float* g, float* m, float*
 	float beta2, float eps, float weight_decay, int64_t* step_state, float grad_scale, void* stream) {
 	VITK_REQUIRE(p && g && m && v && step_state, VITK_ERR_NULL);
 	VITK_REQUIRE(n > 0, VITK_ERR_SHAPE);
-	hipLaunchKernelGGL(adamw_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step_state);
+	hipLaunchKernelGGL(adamw_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step_state, beta1, beta2);
 	VITK_CHECK_LAUNCH();
 	hipLaunchKernelGGL(adamw_kernel, dim3(vitk_stream_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, wd_mask, (bf16_t*)p_bf16, n, lr, beta1, beta2, eps,
 		weight_decay, 1.f, 1.f, grad_scale, (const int64_t*)step_state);

@@ -140,9 +140,28 @@ class FlatAdamW:
 		if bf16_shadow:
 			self.shadow = torch.empty(flat.numel, dtype=torch.bfloat16, device=dev)
 			L.check(L.load().vitk_cast(L.ptr(flat.param), L.ptr(self.shadow), flat.numel, L.F32, L.BF16, L.stream()))
+			# transposed bf16 copies of the 2-D weights (the input-gradient GEMMs read them), refreshed by ONE launch per step
+			self.shadow_t = torch.empty(flat.numel, dtype=torch.bfloat16, device=dev)
+			items, tiles = [], []
 			for p, o in zip(flat.params, flat.offsets):
 				if p.dim() >= 2:
-					ops.register_shadow(p, self.shadow[o:o + p.numel()].view(p.shape))
+					sh = self.shadow[o:o + p.numel()].view(p.shape)
+					ops.register_shadow(p, sh)
+					if p.dim() == 2:
+						rows, cols = p.shape
+						sht = self.shadow_t[o:o + p.numel()].view(cols, rows)
+						ops.register_transposed(sh, sht)
+						for tr in range((rows + 63) // 64):
+							for tc in range((cols + 63) // 64):
+								tiles.append((len(items), tr, tc, 0))
+						items.append((sh.data_ptr(), sht.data_ptr(), rows, cols))
+			self.t_items = torch.tensor(items, dtype=torch.int64).reshape(-1, 4).to(dev)  # vitk_transpose_item: 2 pointers + 2 int64
+			self.t_tiles = torch.tensor(tiles, dtype=torch.int32).reshape(-1, 4).to(dev)
+			self._refresh_transposed()
+
+	def _refresh_transposed(self):
+		if self.shadow is not None and self.t_tiles.shape[0] > 0:
+			L.check(L.load().vitk_transpose_batched(L.ptr(self.t_items), L.ptr(self.t_tiles), self.t_tiles.shape[0], L.BF16, L.stream()))
 
 	def set_step(self, n):
 		"""Set the number of steps taken so far (resuming from a checkpoint)."""
@@ -158,7 +177,8 @@ class FlatAdamW:
 			self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay, L.ptr(self.step_state), grad_scale, L.stream()))
 		if self.shadow is None:
 			ops.invalidate_casts()  # the kernel writes the parameters without bumping their version counters
-		ops.weights_changed()  # cached transposed weight copies are stale now
+		self._refresh_transposed()
+		ops.weights_changed()  # transposed copies cached by ops itself (weights without a kept copy) are stale now
 
 
 class Trainer:

@@ -100,9 +100,23 @@ def weights_changed():
 	_weights_epoch += 1
 
 
+_wt_kept = {}  # id(compute-dtype weight) -> (weakref, transposed copy that its owner keeps up to date)
+
+
+def register_transposed(wc, wt):
+	"""Declare `wt` [in, out] to be a transposed copy of the compute-dtype weight `wc` [out, in] (e.g. a registered
+	bf16 shadow) that the owner refreshes whenever the weight changes (the optimizer does, with one batched launch)."""
+	assert wt.shape == (wc.shape[1], wc.shape[0]) and wt.dtype == wc.dtype and wt.is_contiguous()
+	wid = id(wc)
+	_wt_kept[wid] = (weakref.ref(wc, lambda _r, wid=wid: _wt_kept.pop(wid, None)), wt)
+
+
 def weight_t(wc):
 	"""Transposed copy [in, out] of a weight `wc` [out, in] that is already in the compute dtype (what weight_as
 	returned); cached until the weight changes."""
+	kept = _wt_kept.get(id(wc))
+	if kept is not None and kept[0]() is wc:
+		return kept[1]
 	key = (wc._version, wc.data_ptr(), _weights_epoch)
 	hit = _wt_cache.get(id(wc))
 	if hit is not None and hit[0]() is wc and hit[1] == key:
