@@ -188,11 +188,11 @@ def main():
 			if args.config == "vit_b16" and os.path.exists(tpath):
 				rec = json.load(open(tpath)).get(label)
 				if rec:
-					traffic, traffic_src = round(rec["traffic_bytes"]), "profiles/r1_pmc_hbm_traffic.json"
+					traffic, traffic_src = round(rec["traffic_bytes_per_step"] * args.steps / n), "profiles/r1_pmc_hbm_traffic.json"
 			out["roofline"] = {"bound": "mfma", "kernel": label, "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
 				"frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "launches": n, "avg_launch_ms": round(1e3 * sec / n, 4),
 				"gflop_per_launch": round(fl / n / 1e9, 2),
-				"traffic_unit": "bytes per launch (HBM-side, PMC)", "traffic_source": traffic_src,
+				"traffic_unit": "bytes per vitk_gemm call (HBM-side, PMC)", "traffic_source": traffic_src,
 				"all_gemm_kernels": {k: {"tflops": round(v[0] / v[1] / 1e12, 1), "ms_per_step": round(1e3 * v[1] / args.steps, 3), "launches_per_step": v[2] // args.steps} for k, v in agg.items()}}
 		if not args.no_cpu_baseline and world == 1:
 			out["cpu_baseline"] = cpu_baseline(c)

@@ -3,9 +3,11 @@
 
 FETCH_SIZE / WRITE_SIZE are in KiB at the L2's memory-side interface.  On gfx950 FETCH_SIZE tallies the 128-byte
 requests of wide (16 B per lane) streaming reads at 64 bytes, so it is doubled; WRITE_SIZE is exact for 16-byte-per-lane
-stores.  Writes profiles/<out>.json: {label: {"launches", "fetch_bytes", "write_bytes", "traffic_bytes"}} per launch.
+stores.  Writes profiles/<out>.json: {label: {"kernel_launches_per_step", "fetch_bytes_per_step", "write_bytes_per_step",
+"traffic_bytes_per_step"}} (one vitk_gemm call can be two kernel launches, so the totals are kept per training step and
+bench.py divides by its own count of calls per step).
 
-usage: python tools/pmc_traffic.py fetch_counter_collection.csv write_counter_collection.csv out.json
+usage: python tools/pmc_traffic.py fetch_counter_collection.csv write_counter_collection.csv out.json steps_in_the_profiled_run
 """
 import collections
 import csv
@@ -38,12 +40,13 @@ def per_label(path, counter):
 def main():
 	fetch, fc = per_label(sys.argv[1], "FETCH_SIZE")
 	write, wc = per_label(sys.argv[2], "WRITE_SIZE")
+	steps = float(sys.argv[4])
 	out = {}
 	for lab in fetch:
-		f = 2.0 * 1024.0 * fetch[lab] / fc[lab]
-		w = 1024.0 * write.get(lab, 0.0) / max(wc.get(lab, 1), 1)
-		out[lab] = {"launches": fc[lab], "fetch_bytes": f, "write_bytes": w, "traffic_bytes": f + w}
-		print(f"{lab}: {fc[lab]} launches, fetch {f/1e6:.1f} MB (x2 corrected), write {w/1e6:.1f} MB per launch")
+		f = 2.0 * 1024.0 * fetch[lab] / steps
+		w = 1024.0 * write.get(lab, 0.0) / steps
+		out[lab] = {"kernel_launches_per_step": fc[lab] / steps, "fetch_bytes_per_step": f, "write_bytes_per_step": w, "traffic_bytes_per_step": f + w}
+		print(f"{lab}: {fc[lab] / steps:.1f} kernel launches per step, fetch {f/1e9:.2f} GB (x2 corrected), write {w/1e9:.2f} GB per step")
 	json.dump(out, open(sys.argv[3], "w"), indent=1, sort_keys=True)
 
 
