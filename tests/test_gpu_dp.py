@@ -1,0 +1,96 @@
+"""GPU: the data-parallel step on the real kernels, with the collective replaced by a recorder (one process, one
+device -- the collective itself is covered over gloo on the CPU in test_dp_gloo.py).  What is checked is the part that
+only exists on the GPU path: gradients that the fused block backward adds straight into the flat buffer (gradient sinks)
+report their arrival, every bucket is all-reduced exactly once, while backward is still running, and never before the
+last kernel that writes into it."""
+import pytest
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+pytestmark = pytest.mark.gpu
+
+CFG = dict(d_model=64, n_head=1, n_block=3, n_patch=4, d_ff=128, out_d=10, chw=(3, 16, 16))
+
+
+def _model(dev):
+	from vit_amd.layers import MHA
+	from vit_amd.models import ViT
+
+	class Cfg:
+		attention = MHA
+		norm = nn.LayerNorm
+		activation = "gelu"
+		use_layer_scale = False
+		use_qk_norm = False
+		dropout = 0.0
+	for k, v in CFG.items():
+		setattr(Cfg, k, v)
+	torch.manual_seed(0)
+	return ViT(Cfg()).to(dev)
+
+
+class _Done:
+	def wait(self):
+		return True
+
+
+@pytest.mark.parametrize("bucket_bytes", [1 << 30, 64 << 10, 4 << 10])
+def test_buckets_reduced_once_after_their_last_write(gpu, bucket_bytes, monkeypatch):
+	from vit_amd import dp, ops
+	records = []
+
+	def fake_all_reduce(t, op=None, group=None, async_op=False):
+		torch.cuda.synchronize()  # everything enqueued so far has landed: this is what the collective would read
+		records.append((t.data_ptr(), t.numel(), t.detach().clone()))
+		t.mul_(2.0)  # "sum over two identical ranks"
+		return _Done()
+
+	monkeypatch.setattr(dist, "is_initialized", lambda: True)
+	monkeypatch.setattr(dist, "get_world_size", lambda group=None: 2)
+	monkeypatch.setattr(dist, "broadcast", lambda *a, **k: None)
+	monkeypatch.setattr(dist, "all_reduce", fake_all_reduce)
+	ops.clear_grad_sinks()
+	model = _model(gpu)
+	trainer = dp.Trainer(model, lr=1e-2, weight_decay=0.05, bucket_bytes=bucket_bytes)
+	assert trainer.sync.world == 2
+	g = torch.Generator().manual_seed(7)
+	x = torch.randn(8, 3, 16, 16, generator=g).to(gpu)
+	y = torch.randint(0, 10, (8,), generator=g).to(gpu)
+	base = trainer.flat.grad.data_ptr()
+	for step in range(2):
+		records.clear()
+		trainer.zero_grad()
+		with torch.autocast("cuda", dtype=torch.bfloat16):
+			loss = ops.cross_entropy(model(x), y)
+		loss.backward()
+		during_backward = len(records)
+		arrivals = list(trainer.sync.arrivals)
+		trainer.sync.finish()
+		torch.cuda.synchronize()
+		n_buckets = len(trainer.flat.buckets)
+		assert len(records) == n_buckets and during_backward >= n_buckets - 1
+		assert sorted(arrivals) == list(range(len(trainer.flat.params)))  # every parameter, once
+		spans = sorted(((p - base) // 4, (p - base) // 4 + n) for p, n, _ in records)
+		assert spans == sorted((s, e) for s, e, _ in trainer.flat.buckets)
+		for p, n, snap in records:
+			s = (p - base) // 4
+			# nothing was written into the slice after its collective started
+			assert torch.equal(trainer.flat.grad[s:s + n], 2.0 * snap), f"bucket at {s} was reduced before its last gradient write"
+		trainer.opt.step(0.5)
+	# and the reduced gradient is the gradient: compare with a plain run (no trainer, no sinks)
+	ops.clear_grad_sinks()
+	ref = _model(gpu)
+	with torch.autocast("cuda", dtype=torch.bfloat16):
+		ops.cross_entropy(ref(x), y).backward()
+	monkeypatch.undo()
+	ops.clear_grad_sinks()
+	model2 = _model(gpu)
+	tr2 = dp.Trainer(model2)
+	tr2.zero_grad()
+	with torch.autocast("cuda", dtype=torch.bfloat16):
+		ops.cross_entropy(model2(x), y).backward()
+	from conftest import relerr
+	for (n, p), (_, q) in zip(ref.named_parameters(), model2.named_parameters()):
+		assert relerr(q.grad, p.grad.cpu().double()) < 1e-4, n
+	ops.clear_grad_sinks()

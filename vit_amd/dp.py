@@ -93,10 +93,18 @@ class GradSync:
 		self.pending = [len(idxs) for _, _, idxs in self.flat.buckets]
 		self.works = []
 		self.launched = []
+		self.arrivals = []  # parameter indices in the order their gradients became final (diagnostics / tests)
+		self.arrived = set()
 
 	def _make_hook(self, i):
 		def hook(_param):
+			# A parameter is counted once per step: one whose gradient went to its sink reports from inside the backward
+			# function, and autograd's post-accumulate hook may fire for it as well afterwards.
+			if i in self.arrived:
+				return
+			self.arrived.add(i)
 			b = self.flat.bucket_of[i]
+			self.arrivals.append(i)
 			self.pending[b] -= 1
 			if self.pending[b] == 0:
 				self._launch(b)
