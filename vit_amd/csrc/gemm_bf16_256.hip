@@ -53,6 +53,30 @@ __device__ __forceinline__ bf16x8 read_frag(const char* tile, int base, int s, i
 	}
 }
 
+__device__ __forceinline__ uint32_t lds_addr(const char* p) {
+	return (uint32_t)(uintptr_t)(lds_void_p)(void*)p;
+}
+
+__device__ __forceinline__ bf16x8 join8(s16x4 lo, s16x4 hi) {
+	union {
+		s16x4 h[2];
+		bf16x8 v;
+	} u;
+	u.h[0] = lo;
+	u.h[1] = hi;
+	return u.v;
+}
+
+// read_frag<MN-major> as two inline-asm transposing reads (issued, NOT waited for: the caller retires them)
+__device__ __forceinline__ void read_frag_mn_asm(uint32_t tile_addr, int base, int s, int lane, s16x4& lo, s16x4& hi) {
+	const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
+	const int krow = 32 * s + 8 * g + q;
+	const int col = base + 4 * p;
+	const uint32_t addr = tile_addr + off_mn(krow, col >> 3) + ((p & 1) << 3);
+	asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(addr));
+	asm volatile("ds_read_b64_tr_b16 %0, %1 offset:2048" : "=v"(hi) : "v"(addr));  // rows +4: same swizzle key
+}
+
 // LDS-DMA of one 256 x 64 operand tile: 32 pieces of 1 KiB, 4 per wave.  Every source address is a wave-uniform
 // 64-bit base (scalar registers) plus a 32-bit per-lane byte offset that is recomputed from the lane id on each call
 // (the empty asm keeps the compiler from hoisting 16 loop-invariant address registers into the MFMA loop, where the
@@ -140,6 +164,33 @@ __device__ __forceinline__ void mma_stage(const char* sa, const char* sb, f32x4 
 			if constexpr (reads > 0) __builtin_amdgcn_sched_group_barrier(0x100, reads, 0);
 			__builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
 		});
+	} else if constexpr (BLAYOUT == VITK_MN_MAJOR) {
+		// Both operands MN-major (weight gradients).  The transposing reads are issued as inline asm: for the builtin the
+		// compiler puts an s_waitcnt vmcnt(0) in front of the first read after an LDS-DMA request (it cannot tell that the
+		// request goes to the OTHER stage), which would make every K step wait for the next one's operands.  The asm
+		// reads carry no such ordering; their results are retired by an explicit lgkmcnt(0) that names all fragment
+		// registers, so no MFMA can be scheduled above it.
+		if constexpr (SPREAD_DMA) {
+#pragma unroll
+			for (int j = 0; j < 8; ++j) dma(j);
+		}
+		const uint32_t abase = lds_addr(sa), bbase = lds_addr(sb);
+#pragma unroll
+		for (int s = 0; s < 2; ++s) {
+			s16x4 xh[8][2], wh[4][2];
+#pragma unroll
+			for (int j = 0; j < 4; ++j) read_frag_mn_asm(bbase, wn + 16 * j, s, lane, wh[j][0], wh[j][1]);
+#pragma unroll
+			for (int i = 0; i < 8; ++i) read_frag_mn_asm(abase, wm + 16 * i, s, lane, xh[i][0], xh[i][1]);
+			asm volatile("s_waitcnt lgkmcnt(0)"
+						 : "+v"(wh[0][0]), "+v"(wh[0][1]), "+v"(wh[1][0]), "+v"(wh[1][1]), "+v"(wh[2][0]), "+v"(wh[2][1]), "+v"(wh[3][0]), "+v"(wh[3][1]), "+v"(xh[0][0]),
+						   "+v"(xh[0][1]), "+v"(xh[1][0]), "+v"(xh[1][1]), "+v"(xh[2][0]), "+v"(xh[2][1]), "+v"(xh[3][0]), "+v"(xh[3][1]), "+v"(xh[4][0]), "+v"(xh[4][1]),
+						   "+v"(xh[5][0]), "+v"(xh[5][1]), "+v"(xh[6][0]), "+v"(xh[6][1]), "+v"(xh[7][0]), "+v"(xh[7][1]));
+#pragma unroll
+			for (int i = 0; i < 8; ++i)
+#pragma unroll
+				for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(join8(wh[j][0], wh[j][1]), join8(xh[i][0], xh[i][1]), acc[i][j], 0, 0, 0);
+		}
 	} else {
 		if constexpr (SPREAD_DMA) {
 #pragma unroll
@@ -254,18 +305,20 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_256_kernel(BigArgs a) {
 	for (int t = 0; t < nt; ++t) {
 		const char* sa = smem + (t & 1) * STAGE_BYTES;
 		const char* sb = sa + TILE_BYTES;
-		if (t + 1 < nt) {
-			char* da = smem + ((t + 1) & 1) * STAGE_BYTES;
-			const int k0 = k_begin + (t + 1) * BK;
-			stage_tile<ALAYOUT>(da, A, g.lda, m0, g.M, k0, wave, lane);
-			stage_tile<BLAYOUT>(da + TILE_BYTES, B, g.ldb, n0, g.N, k0, wave, lane);
-		}
+		// (before the next stage's LDS-DMA is issued: the compiler orders plain LDS loads behind every LDS-DMA in flight,
+		// which would make this K step wait for the next one's operands)
 		if constexpr (ALAYOUT == VITK_MN_MAJOR) {
 			if (do_colsum && (k_begin / BK + t) % a.tiles_n == tn) {
 				const int c = tid & 255, kr0 = (tid >> 8) * 32;
 #pragma unroll 8
 				for (int kr = kr0; kr < kr0 + 32; ++kr) csum += (float)*reinterpret_cast<const bf16_t*>(sa + off_mn(kr, c >> 3) + (c & 7) * 2);
 			}
+		}
+		if (t + 1 < nt) {
+			char* da = smem + ((t + 1) & 1) * STAGE_BYTES;
+			const int k0 = k_begin + (t + 1) * BK;
+			stage_tile<ALAYOUT>(da, A, g.lda, m0, g.M, k0, wave, lane);
+			stage_tile<BLAYOUT>(da + TILE_BYTES, B, g.ldb, n0, g.N, k0, wave, lane);
 		}
 		mma_stage<ALAYOUT, BLAYOUT>(sa, sb, acc, wm, wn, lane);
 		__syncthreads();  // next stage landed (vmcnt(0) drained by the fence) and everyone is done with this one
