@@ -31,7 +31,8 @@ int main(int argc, char** argv) {
 	d.in_dtype = d.out_dtype = VITK_BF16;
 	if (b_mn) { d.b_layout = VITK_MN_MAJOR; d.ldb = N; }
 	d.epilogue = epi;
-	if (epi == VITK_EPI_ACT) { d.act = VITK_ACT_GELU; d.bias = bias; d.out2 = OUT2; d.ld_out2 = N; }
+	const int variant = argc > 6 ? atoi(argv[6]) : 0;  // 1: no pre-activation output, 2: identity activation
+	if (epi == VITK_EPI_ACT) { d.act = variant == 2 ? VITK_ACT_NONE : VITK_ACT_GELU; d.bias = bias; d.out2 = variant == 1 ? nullptr : OUT2; d.ld_out2 = N; }
 	if (epi == VITK_EPI_RESIDUAL) { d.bias = bias; d.aux = AUX; d.ld_aux = N; }
 	if (epi == VITK_EPI_ACTGRAD) { d.act = VITK_ACT_GELU; d.aux = AUX; d.ld_aux = N; }
 	hipEvent_t e0, e1;
@@ -90,7 +91,9 @@ int main(int argc, char** argv) {
 			if (s[0] == 0) continue;
 			++cnt;
 			start += (s[0] - tmin) * 0.01;
-			for (int i = 0; i < 4; ++i) w[i] += (s[i + 1] - s[i]) * 0.01;
+			w[1] += (s[2] - s[0]) * 0.01;
+			w[2] += (s[3] - s[2]) * 0.01;
+			w[3] += (s[4] - s[3]) * 0.01;
 		}
 		if (cnt == 0) break;
 		printf("round %2d: %3d wgs  start %7.2f us | wait first stage %5.2f | main loop %6.2f | next-stage issue %5.2f | epilogue %5.2f\n", r, cnt, start / cnt, w[0] / cnt,

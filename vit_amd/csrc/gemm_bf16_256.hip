@@ -24,6 +24,7 @@ constexpr int CT_LD = 260;                // floats per row of the epilogue imag
 constexpr int CB_LD = 264;                // bf16 per row of the bf16 epilogue image (256 + 8 pad)
 constexpr int LDS_BYTES = 256 * CB_LD * 2;  // 135,168 B >= float image of 128 rows (133,120 B) >= 2 stages (131,072 B)
 
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void* lds_void_p;
 typedef const __attribute__((address_space(1))) void* gbl_void_p;
 
@@ -211,6 +212,18 @@ __device__ __forceinline__ void mma_stage(const char* sa, const char* sb, f32x4 
 	}
 }
 
+// Activation in the bf16-output epilogues: GELU known at compile time takes the transcendental-free form.
+template <int ACT>
+__device__ __forceinline__ float act_fwd(float u, int act_rt) {
+	if constexpr (ACT == VITK_ACT_GELU) return gelu_bf16(u);
+	else return act_apply(u, act_rt);
+}
+template <int ACT>
+__device__ __forceinline__ float act_bwd(float u, int act_rt) {
+	if constexpr (ACT == VITK_ACT_GELU) return gelu_deriv_bf16(u);
+	else return act_deriv(u, act_rt);
+}
+
 struct BigArgs {
 	GemmDev g;
 	int tiles_m, tiles_n, splits, k_per_split;
@@ -378,7 +391,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_256_kernel(BigArgs a) {
 						}
 					}
 #pragma unroll
-					for (int r = 0; r < 4; ++r) v[r] = act_apply(v[r], ACT >= 0 ? ACT : g.act);
+					for (int r = 0; r < 4; ++r) v[r] = act_fwd<ACT>(v[r], g.act);
 				} else if (EPI == VITK_EPI_RESIDUAL || EPI == VITK_EPI_ACTGRAD) {
 					float x4[4] = {0.f, 0.f, 0.f, 0.f};
 					if (in) {
@@ -395,7 +408,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_256_kernel(BigArgs a) {
 						for (int r = 0; r < 4; ++r) v[r] = x4[r] + ((g.gamma != nullptr && nb + r < g.N) ? g.gamma[nb + r] : 1.f) * v[r];
 					} else {
 #pragma unroll
-						for (int r = 0; r < 4; ++r) v[r] *= act_deriv(x4[r], ACT >= 0 ? ACT : g.act);
+						for (int r = 0; r < 4; ++r) v[r] *= act_bwd<ACT>(x4[r], g.act);
 					}
 				}
 				bf16x4 pk;
@@ -549,20 +562,31 @@ __device__ __forceinline__ void epilogue_wave_private(const BigArgs& a, const f3
 		});
 		return;
 	}
-	bf16x8 auxv[2][4];
+	// Operand rows (residual / pre-activation) of the NEXT quarter are requested at the top of each quarter, as inline
+	// asm with a wave-uniform row base in scalar registers and one 32-bit lane offset, and retired by a COUNTED wait
+	// that leaves this quarter's requests and the previous quarter's stores in flight.  (Written as plain loads, the
+	// compiler sinks them to their uses and waits vmcnt(0) there, i.e. for every store issued before them.)  The
+	// "memory" clobbers pin the stores between the asm statements, which the count relies on.
+	u32x4 auxv[2][4];
+	const uint32_t aux_voff = (uint32_t)(r8 * (int)g.ld_aux + 8 * c8) * 2u;
 	if (HAS_AUX) {
 #pragma unroll
-		for (int it = 0; it < 4; ++it) auxv[0][it] = er.aux0[it];
+		for (int it = 0; it < 4; ++it) auxv[0][it] = __builtin_bit_cast(u32x4, er.aux0[it]);
 	}
 	static_for<0, 4>([&](auto qc) {
 		constexpr int qq = decltype(qc)::value;
-		// operand rows of the NEXT quarter: requested one LDS round trip ahead of their use
 		if (HAS_AUX && qq < 3) {
 #pragma unroll
 			for (int it = 0; it < 4; ++it) {
-				const int64_t m = m0w + 32 * (qq + 1) + 8 * it + r8;
-				auxv[(qq + 1) & 1][it] = *reinterpret_cast<const bf16x8*>(aux + m * g.ld_aux + nb);
+				const bf16_t* rowbase = aux + (m0w + 32 * (qq + 1) + 8 * it) * g.ld_aux + n0w;  // wave-uniform
+				asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(auxv[(qq + 1) & 1][it]) : "v"(aux_voff), "s"(rowbase) : "memory");
 			}
+		}
+		if (HAS_AUX && qq > 0) {
+			// issued after the rows needed now: 4 stores of the previous quarter (+ 4 requests just above)
+			u32x4(&cur)[4] = auxv[qq & 1];
+			if constexpr (qq < 3) asm volatile("s_waitcnt vmcnt(8)" : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3])::"memory");
+			else asm volatile("s_waitcnt vmcnt(4)" : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3])::"memory");
 		}
 		write_quarter(qc);
 #pragma unroll
@@ -584,14 +608,25 @@ __device__ __forceinline__ void epilogue_wave_private(const BigArgs& a, const f3
 					}
 					*reinterpret_cast<bf16x8*>(out2 + m * g.ld_out2 + nb) = pre;
 				}
+				if constexpr (ACT == VITK_ACT_GELU) {
+					gelu_bf16_n<8>(v);
+				} else {
 #pragma unroll
-				for (int e = 0; e < 8; ++e) v[e] = act_apply(v[e], ACT >= 0 ? ACT : g.act);
+					for (int e = 0; e < 8; ++e) v[e] = act_apply(v[e], g.act);
+				}
 			} else if (EPI == VITK_EPI_RESIDUAL) {
 #pragma unroll
-				for (int e = 0; e < 8; ++e) v[e] = (float)auxv[qq & 1][it][e] + er.gamma8[e] * v[e];
+				for (int e = 0; e < 8; ++e) v[e] = (float)__builtin_bit_cast(bf16x8, auxv[qq & 1][it])[e] + er.gamma8[e] * v[e];
 			} else if (EPI == VITK_EPI_ACTGRAD) {
+				float u[8];
 #pragma unroll
-				for (int e = 0; e < 8; ++e) v[e] *= act_deriv((float)auxv[qq & 1][it][e], ACT >= 0 ? ACT : g.act);
+				for (int e = 0; e < 8; ++e) u[e] = (float)__builtin_bit_cast(bf16x8, auxv[qq & 1][it])[e];
+				if constexpr (ACT == VITK_ACT_GELU) {
+					gelu_deriv_bf16_n<8>(v, u);
+				} else {
+#pragma unroll
+					for (int e = 0; e < 8; ++e) v[e] *= act_deriv(u[e], g.act);
+				}
 			}
 			bf16x8 pk;
 #pragma unroll

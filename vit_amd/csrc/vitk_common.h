@@ -90,6 +90,64 @@ __device__ __forceinline__ float gelu_cdf(float u, float& e) {
 	return u >= 0.f ? 1.0f - half_erfc : half_erfc;
 }
 
+// Phi(u) for results that are rounded to bf16 anyway: 0.5 + uc * Q(uc^2 / c^2) with uc = u clamped to +-c, c = 4.25
+// (|error| <= 1.2e-5 absolute, 1 - Phi(c) = 1.1e-5).  No transcendental instruction (those issue at quarter rate):
+// a clamp and 11 multiply-adds, which the compiler packs two elements per instruction.
+__device__ __forceinline__ float gelu_cdf_poly(float u) {
+	const float uc = __builtin_amdgcn_fmed3f(u, -4.25f, 4.25f);
+	const float t = uc * uc * (1.0f / (4.25f * 4.25f));
+	float q = fmaf(6.304869652e-01f, t, -3.341864109e+00f);
+	q = fmaf(q, t, 7.832413673e+00f);
+	q = fmaf(q, t, -1.081737137e+01f);
+	q = fmaf(q, t, 9.943633080e+00f);
+	q = fmaf(q, t, -6.532705307e+00f);
+	q = fmaf(q, t, 3.202498674e+00f);
+	q = fmaf(q, t, -1.198347330e+00f);
+	q = fmaf(q, t, 3.989023268e-01f);
+	return fmaf(uc, q, 0.5f);
+}
+__device__ __forceinline__ float gelu_bf16(float u) { return u * gelu_cdf_poly(u); }
+__device__ __forceinline__ float gelu_deriv_bf16(float u) { return fmaf(u * 0.39894228040143268f, __expf(-0.5f * u * u), gelu_cdf_poly(u)); }
+
+// The same for N elements at once, one polynomial step over all elements at a time: consecutive instructions are then
+// independent (written element by element, each packed multiply-add waits on the one before it).
+template <int N>
+__device__ __forceinline__ void gelu_cdf_poly_n(const float (&u)[N], float (&cdf)[N]) {
+	constexpr float C[9] = {3.989023268e-01f, -1.198347330e+00f, 3.202498674e+00f, -6.532705307e+00f, 9.943633080e+00f,
+		-1.081737137e+01f, 7.832413673e+00f, -3.341864109e+00f, 6.304869652e-01f};
+	float uc[N], t[N], q[N];
+#pragma unroll
+	for (int e = 0; e < N; ++e) uc[e] = __builtin_amdgcn_fmed3f(u[e], -4.25f, 4.25f);
+#pragma unroll
+	for (int e = 0; e < N; ++e) t[e] = uc[e] * uc[e] * (1.0f / (4.25f * 4.25f));
+#pragma unroll
+	for (int e = 0; e < N; ++e) q[e] = fmaf(C[8], t[e], C[7]);
+#pragma unroll
+	for (int c = 6; c >= 0; --c) {
+#pragma unroll
+		for (int e = 0; e < N; ++e) q[e] = fmaf(q[e], t[e], C[c]);
+	}
+#pragma unroll
+	for (int e = 0; e < N; ++e) cdf[e] = fmaf(uc[e], q[e], 0.5f);
+}
+template <int N>
+__device__ __forceinline__ void gelu_bf16_n(float (&v)[N]) {
+	float cdf[N];
+	gelu_cdf_poly_n<N>(v, cdf);
+#pragma unroll
+	for (int e = 0; e < N; ++e) v[e] *= cdf[e];
+}
+// v[e] *= gelu'(u[e])
+template <int N>
+__device__ __forceinline__ void gelu_deriv_bf16_n(float (&v)[N], const float (&u)[N]) {
+	float cdf[N], ex[N];
+#pragma unroll
+	for (int e = 0; e < N; ++e) ex[e] = __builtin_amdgcn_exp2f(u[e] * u[e] * (-0.5f * 1.44269504088896341f));
+	gelu_cdf_poly_n<N>(u, cdf);
+#pragma unroll
+	for (int e = 0; e < N; ++e) v[e] *= fmaf(u[e] * 0.39894228040143268f, ex[e], cdf[e]);
+}
+
 __device__ __forceinline__ float act_apply(float u, int act) {
 	switch (act) {
 		case VITK_ACT_GELU: {
