@@ -156,6 +156,20 @@ int vitk_attention_bwd(const void* dout, const void* q, const void* k, const voi
 	int64_t B, int64_t n_head, int64_t Sq, int64_t Skv, int64_t dh,
 	int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t lddq, int64_t lddk, int64_t lddv,
 	float scale, int dtype, void* stream);
+/* The same with dropout on the attention probabilities: the `dropout_p` argument of
+ * F.scaled_dot_product_attention in training mode (layers/attention.py:41,86):
+ * out = (softmax(q k^T * scale) o M / (1 - p)) v with a keep mask M.  M is a pure function of
+ * (seed, batch, head, query, key) that the backward regenerates from the same `dropout_p` and `seed`
+ * (nothing is stored); dropout_p = 0 is the plain attention above.  The mask comes from a counter-based
+ * hash, not from torch's Philox stream: the distribution matches the reference, the individual draws do not. */
+int vitk_attention_fwd_dropout(const void* q, const void* k, const void* v, void* out, float* lse,
+	int64_t B, int64_t n_head, int64_t Sq, int64_t Skv, int64_t dh,
+	int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, float scale, float dropout_p, uint64_t seed, int dtype, void* stream);
+int vitk_attention_bwd_dropout(const void* dout, const void* q, const void* k, const void* v, const void* out, const float* lse,
+	void* dq, void* dk, void* dv,
+	int64_t B, int64_t n_head, int64_t Sq, int64_t Skv, int64_t dh,
+	int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t lddq, int64_t lddk, int64_t lddv,
+	float scale, float dropout_p, uint64_t seed, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Bandwidth-bound elementwise / reduction kernels.

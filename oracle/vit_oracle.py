@@ -192,6 +192,70 @@ def sdpa_bwd(do, q, k, v, out, lse, scale=None):
 	return dq, dk, dv
 
 
+def _hash32(x):
+	"""32-bit integer mixer of the attention dropout mask (numpy uint64 arithmetic masked to 32 bits)."""
+	import numpy as np
+	m = np.uint64(0xFFFFFFFF)
+	x = x & m
+	x ^= x >> np.uint64(16)
+	x = (x * np.uint64(0x7feb352d)) & m
+	x ^= x >> np.uint64(15)
+	x = (x * np.uint64(0x846ca68b)) & m
+	x ^= x >> np.uint64(16)
+	return x
+
+
+def attn_dropout_keep(seed, p, B, H, Sq, Skv):
+	"""Keep mask of the attention-probability dropout (the `dropout_p` of F.scaled_dot_product_attention,
+	layers/attention.py:41,86), as the HIP kernels generate it: values 0 or 1/(1 - p'), shape [B, H, Sq, Skv], with
+	p' = p quantised to 1/65536.  The reference draws its mask from torch's Philox stream, which cannot be reproduced;
+	the tests therefore hand THIS mask to the reference arithmetic below (distribution parity, exact arithmetic parity)."""
+	import numpy as np
+	m = np.uint64(0xFFFFFFFF)
+	thr = min(int(round(p * 65536.0)), 65535)
+	if p > 0 and thr == 0:
+		thr = 1
+	seed_lo, seed_hi = np.uint64(seed & 0xFFFFFFFF), np.uint64((seed >> 32) & 0xFFFFFFFF)
+	bh = np.arange(B * H, dtype=np.uint64)
+	head_key = _hash32(seed_lo ^ _hash32(seed_hi ^ bh))  # [B*H]
+	q = np.arange(Sq, dtype=np.uint64)
+	row_key = _hash32((head_key[:, None] + q[None, :] * np.uint64(0x9E3779B1)) & m)  # [B*H, Sq]
+	k = np.arange(Skv, dtype=np.uint64)
+	pair = ((k >> np.uint64(1)) * np.uint64(0x85EBCA6B) + np.uint64(0x1B873593)) & m
+	bits = _hash32(row_key[:, :, None] ^ pair[None, None, :])  # [B*H, Sq, Skv]
+	field = np.where((k & np.uint64(1)) == 1, bits >> np.uint64(16), bits & np.uint64(0xFFFF))
+	keep = (field >= np.uint64(thr)).astype(np.float64) * (65536.0 / (65536 - thr))
+	return torch.from_numpy(keep.reshape(B, H, Sq, Skv))
+
+
+def sdpa_dropout_fwd(q, k, v, keep, scale=None):
+	"""sdpa_fwd with dropout on the probabilities: out = (softmax(s) * keep) @ v; lse is that of the full softmax."""
+	dh = q.shape[-1]
+	scale = (1.0 / math.sqrt(dh)) if scale is None else scale
+	s = (q @ k.transpose(-1, -2)) * scale
+	m = s.max(-1, keepdim=True).values
+	p = torch.exp(s - m)
+	l = p.sum(-1, keepdim=True)
+	out = ((p / l) * keep.to(p.dtype)) @ v
+	lse = (m + torch.log(l)).squeeze(-1)
+	return out, lse
+
+
+def sdpa_dropout_bwd(do, q, k, v, out, lse, keep, scale=None):
+	dh = q.shape[-1]
+	scale = (1.0 / math.sqrt(dh)) if scale is None else scale
+	keep = keep.to(q.dtype)
+	s = (q @ k.transpose(-1, -2)) * scale
+	p = torch.exp(s - lse.unsqueeze(-1))
+	dv = (p * keep).transpose(-1, -2) @ do
+	dp = (do @ v.transpose(-1, -2)) * keep
+	delta = (do * out).sum(-1, keepdim=True)
+	ds = p * (dp - delta) * scale
+	dq = ds @ k
+	dk = ds.transpose(-1, -2) @ q
+	return dq, dk, dv
+
+
 def split_heads(x, h):
 	"""'b s (h d) -> b h s d' (layers/attention.py:31-33,80-82)."""
 	b, s, hd = x.shape

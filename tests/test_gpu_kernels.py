@@ -263,6 +263,41 @@ def test_attention(gpu, dtype, B, h, Sq, Skv, dh):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,h,Sq,Skv,dh,p", [(2, 12, 197, 197, 64, 0.3), (2, 3, 65, 65, 64, 0.1), (2, 2, 50, 13, 24, 0.3), (1, 2, 300, 300, 64, 0.5), (2, 2, 64, 16, 32, 0.3)])
+def test_attention_dropout(gpu, dtype, B, h, Sq, Skv, dh, p):
+	"""Attention with dropout on the probabilities (the reference's training path, layers/attention.py:41,86): the
+	kernels' mask is regenerated on the CPU and handed to the oracle, so forward and all three gradients are compared
+	exactly as without dropout; the mask itself is checked for its keep rate."""
+	from vit_amd import ops
+	d = h * dh
+	seed = 0x1234_5678_9ABC_DEF0 + Sq
+	q, qr = rnd((B * Sq, d), dtype, gpu, seed=1)
+	k, kr = rnd((B * Skv, d), dtype, gpu, seed=2)
+	v, vr = rnd((B * Skv, d), dtype, gpu, seed=3)
+	do, dor = rnd((B * Sq, d), dtype, gpu, seed=4)
+	keep = O.attn_dropout_keep(seed, p, B, h, Sq, Skv)
+	rate = (keep > 0).double().mean().item()
+	assert abs(rate - (1 - p)) < 4 * (p * (1 - p) / keep.numel()) ** 0.5 + 1e-4
+	out, lse = ops.attention_fwd(q, k, v, B, h, Sq, Skv, dh, drop=(p, seed))
+	q4 = O.split_heads(qr.reshape(B, Sq, d), h)
+	k4 = O.split_heads(kr.reshape(B, Skv, d), h)
+	v4 = O.split_heads(vr.reshape(B, Skv, d), h)
+	o_ref, lse_ref = O.sdpa_dropout_fwd(q4, k4, v4, keep)
+	assert relerr(out, O.merge_heads(o_ref).reshape(B * Sq, d)) < TOL[dtype]
+	assert relerr(lse, lse_ref) < 1e-4
+	# a different seed gives a different mask
+	out2, _ = ops.attention_fwd(q, k, v, B, h, Sq, Skv, dh, drop=(p, seed + 1))
+	assert relerr(out2, O.merge_heads(o_ref).reshape(B * Sq, d)) > 10 * TOL[dtype]
+	dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+	ops.attention_bwd(do, q, k, v, out, lse, dq, dk, dv, B, h, Sq, Skv, dh, drop=(p, seed))
+	do4 = O.split_heads(dor.reshape(B, Sq, d), h)
+	dq_r, dk_r, dv_r = O.sdpa_dropout_bwd(do4, q4, k4, v4, o_ref, lse_ref, keep)
+	assert relerr(dq, O.merge_heads(dq_r).reshape(B * Sq, d)) < TOL[dtype]
+	assert relerr(dk, O.merge_heads(dk_r).reshape(B * Skv, d)) < TOL[dtype]
+	assert relerr(dv, O.merge_heads(dv_r).reshape(B * Skv, d)) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_attention_strided_qkv(gpu, dtype):
 	"""q/k/v as column slices of one fused [rows, 3d] buffer (the layout MHA uses)."""
 	from vit_amd import ops

@@ -125,7 +125,6 @@ def test_dropout_block_runs(gpu):
 		use_layer_scale = True; use_qk_norm = False; attention = MHA
 	torch.manual_seed(0)
 	blk = ViTBlock(Cfg()).to(gpu)
-	blk.attn.dropout.p = 0.0  # attention-probability dropout is not implemented
 	x = torch.randn(2, 9, 64, device=gpu, requires_grad=True)
 	y, reg = blk(x)
 	assert reg == 0.0 and torch.isfinite(y).all()
@@ -139,6 +138,62 @@ def test_dropout_block_runs(gpu):
 	blk.train()
 	y_fused, _ = blk(x)
 	assert relerr(y_eval, y_fused) < 1e-5
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_mha_attention_dropout_module(gpu, dtype):
+	"""MHA in training mode with the reference's default dropout (config.py: dropout = 0.3): the draw is repeatable under
+	torch.manual_seed, differs from call to call, its gradients are finite, and its mean over many draws approaches the
+	eval-mode output (the kept probabilities are rescaled by 1 / (1 - p))."""
+	from vit_amd import ops
+	from vit_amd.layers import MHA
+
+	class Cfg:
+		d_model = 128; n_head = 2; dropout = 0.3; use_qk_norm = False
+	torch.manual_seed(0)
+	m = MHA(Cfg()).to(gpu)
+	x = torch.randn(2, 50, 128, device=gpu).to(dtype).requires_grad_()
+	m.train()
+	torch.manual_seed(7)
+	ops._dropout_calls[0] = 0
+	y1 = m(x)
+	y2 = m(x)
+	torch.manual_seed(7)
+	ops._dropout_calls[0] = 0
+	y1b = m(x)
+	assert torch.equal(y1, y1b) and not torch.equal(y1, y2)
+	y1.float().square().sum().backward()
+	assert torch.isfinite(x.grad).all() and all(torch.isfinite(p.grad).all() for p in m.parameters())
+	with torch.no_grad():
+		acc = torch.zeros_like(y1, dtype=torch.float32)
+		n = 400
+		for _ in range(n):
+			acc += m(x).float()
+		m.eval()
+		y_eval = m(x).float()
+	assert relerr(acc / n, y_eval) < 0.1
+
+
+def test_reference_config_trains(gpu):
+	"""A ViT built from the reference's own hyper-parameter style (dropout = 0.3, config.py:25) runs a training step:
+	attention-probability dropout, branch dropout and both feed-forward dropouts are all active."""
+	from vit_amd.models import ViT
+	from vit_amd.layers import MHA
+
+	class Cfg:
+		d_model = 64; n_head = 2; n_block = 2; n_patch = 4; d_ff = 128; out_d = 10; chw = (3, 16, 16); dropout = 0.3
+		activation = "gelu"; norm = nn.LayerNorm; attention = MHA; use_layer_scale = False; use_qk_norm = False
+	torch.manual_seed(0)
+	model = ViT(Cfg()).to(gpu).train()
+	x = torch.randn(8, 3, 16, 16, device=gpu)
+	y = torch.randint(0, 10, (8,), device=gpu)
+	with torch.autocast("cuda", dtype=torch.bfloat16):
+		out = model(x)
+		logits = out[0] if isinstance(out, tuple) else out
+	loss = torch.nn.functional.cross_entropy(logits.float(), y)
+	loss.backward()
+	assert torch.isfinite(loss)
+	assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in model.parameters())
 
 
 def make_cvt(c, gpu):

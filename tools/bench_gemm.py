@@ -27,7 +27,7 @@ def timeit(fn, iters=20, reps=3):
 	return best
 
 
-for name, m, n, k in shapes:
+for name, m, n, k in (shapes if __name__ == "__main__" else []):
 	x = torch.randn(m, k, device=dev).to(torch.bfloat16)
 	w = (torch.randn(n, k, device=dev) * 0.05).to(torch.bfloat16)
 	dy = torch.randn(m, n, device=dev).to(torch.bfloat16)

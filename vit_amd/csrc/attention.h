@@ -11,7 +11,31 @@ struct AttnArgs {
 	int B, n_head, Sq, Skv, dh;
 	int64_t ldq, ldk, ldv, ldo, lddq, lddk, lddv;
 	float scale;
+	// attention-probability dropout (F.scaled_dot_product_attention's dropout_p, layers/attention.py:41,86): a
+	// probability is dropped when its 16 mask bits are below drop_thr16 (= p * 65536, 0 = no dropout) and the kept
+	// ones are scaled by drop_scale = 65536 / (65536 - drop_thr16)
+	uint32_t drop_thr16, seed_lo, seed_hi;
+	float drop_scale;
 };
+
+// The dropout mask is a pure function of (seed, batch * n_head + head, query, key), so the forward and both backward
+// kernels regenerate it instead of storing it: one 32-bit hash per (query, pair of keys), 16 bits per key.
+__host__ __device__ __forceinline__ uint32_t vitk_hash32(uint32_t x) {
+	x ^= x >> 16;
+	x *= 0x7feb352du;
+	x ^= x >> 15;
+	x *= 0x846ca68bu;
+	x ^= x >> 16;
+	return x;
+}
+__device__ __forceinline__ uint32_t attn_head_key(const AttnArgs& a, int bh) { return vitk_hash32(a.seed_lo ^ vitk_hash32(a.seed_hi ^ (uint32_t)bh)); }
+__device__ __forceinline__ uint32_t attn_row_key(uint32_t head_key, int q) { return vitk_hash32(head_key + (uint32_t)q * 0x9E3779B1u); }
+__device__ __forceinline__ uint32_t attn_pair_bits(uint32_t row_key, int key_pair) { return vitk_hash32(row_key ^ ((uint32_t)key_pair * 0x85EBCA6Bu + 0x1B873593u)); }
+// multiplier (0 or drop_scale) of the probability of key `key`, given the bits of its pair
+__device__ __forceinline__ float attn_keep(uint32_t pair_bits, int key, uint32_t thr16, float drop_scale) {
+	const uint32_t bits = (key & 1) ? (pair_bits >> 16) : (pair_bits & 0xffffu);
+	return bits >= thr16 ? drop_scale : 0.f;
+}
 
 int vitk_attention_generic(const AttnArgs& a, bool bwd, int dtype, hipStream_t st);
 // bf16 MFMA kernels; return VITK_ERR_UNSUPPORTED when the shape does not qualify

@@ -11,8 +11,22 @@ static int check_common(const AttnArgs& a) {
 	return VITK_OK;
 }
 
-extern "C" int vitk_attention_fwd(const void* q, const void* k, const void* v, void* out, float* lse, int64_t B, int64_t n_head, int64_t Sq,
-	int64_t Skv, int64_t dh, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, float scale, int dtype, void* stream) {
+// dropout_p in [0, 1): quantised to 1/65536 (the kept probabilities are rescaled by the quantised keep rate, so the
+// expectation of the output is exact); 0 switches dropout off
+static int set_dropout(AttnArgs& a, float dropout_p, uint64_t seed) {
+	VITK_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, VITK_ERR_SHAPE);
+	uint32_t thr = (uint32_t)lrintf(dropout_p * 65536.f);
+	if (thr > 65535u) thr = 65535u;
+	if (dropout_p > 0.f && thr == 0) thr = 1;
+	a.drop_thr16 = thr;
+	a.drop_scale = 65536.f / (float)(65536u - thr);
+	a.seed_lo = (uint32_t)seed;
+	a.seed_hi = (uint32_t)(seed >> 32);
+	return VITK_OK;
+}
+
+extern "C" int vitk_attention_fwd_dropout(const void* q, const void* k, const void* v, void* out, float* lse, int64_t B, int64_t n_head, int64_t Sq,
+	int64_t Skv, int64_t dh, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, float scale, float dropout_p, uint64_t seed, int dtype, void* stream) {
 	VITK_REQUIRE(q && k && v && out && lse, VITK_ERR_NULL);
 	VITK_REQUIRE(B < (1ll << 31) && n_head < (1ll << 31) && Sq < (1ll << 31) && Skv < (1ll << 31) && dh < (1ll << 31), VITK_ERR_SHAPE);
 	AttnArgs a{};
@@ -22,13 +36,20 @@ extern "C" int vitk_attention_fwd(const void* q, const void* k, const void* v, v
 	a.scale = scale > 0.f ? scale : 1.0f / sqrtf((float)dh);
 	int rc = check_common(a);
 	if (rc != VITK_OK) return rc;
+	rc = set_dropout(a, dropout_p, seed);
+	if (rc != VITK_OK) return rc;
 	if (vitk_attention_mfma_ok(a, dtype)) return vitk_attention_mfma(a, false, (hipStream_t)stream);
 	return vitk_attention_generic(a, false, dtype, (hipStream_t)stream);
 }
 
-extern "C" int vitk_attention_bwd(const void* dout, const void* q, const void* k, const void* v, const void* out, const float* lse, void* dq,
+extern "C" int vitk_attention_fwd(const void* q, const void* k, const void* v, void* out, float* lse, int64_t B, int64_t n_head, int64_t Sq,
+	int64_t Skv, int64_t dh, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, float scale, int dtype, void* stream) {
+	return vitk_attention_fwd_dropout(q, k, v, out, lse, B, n_head, Sq, Skv, dh, ldq, ldk, ldv, ldo, scale, 0.f, 0, dtype, stream);
+}
+
+extern "C" int vitk_attention_bwd_dropout(const void* dout, const void* q, const void* k, const void* v, const void* out, const float* lse, void* dq,
 	void* dk, void* dv, int64_t B, int64_t n_head, int64_t Sq, int64_t Skv, int64_t dh, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
-	int64_t lddq, int64_t lddk, int64_t lddv, float scale, int dtype, void* stream) {
+	int64_t lddq, int64_t lddk, int64_t lddv, float scale, float dropout_p, uint64_t seed, int dtype, void* stream) {
 	VITK_REQUIRE(dout && q && k && v && out && lse && dq && dk && dv, VITK_ERR_NULL);
 	VITK_REQUIRE(B < (1ll << 31) && n_head < (1ll << 31) && Sq < (1ll << 31) && Skv < (1ll << 31) && dh < (1ll << 31), VITK_ERR_SHAPE);
 	AttnArgs a{};
@@ -41,6 +62,15 @@ extern "C" int vitk_attention_bwd(const void* dout, const void* q, const void* k
 	if (rc != VITK_OK) return rc;
 	const int64_t hd = (int64_t)a.n_head * a.dh;
 	VITK_REQUIRE(lddq >= hd && lddk >= hd && lddv >= hd, VITK_ERR_SHAPE);
+	rc = set_dropout(a, dropout_p, seed);
+	if (rc != VITK_OK) return rc;
 	if (vitk_attention_mfma_ok(a, dtype)) return vitk_attention_mfma(a, true, (hipStream_t)stream);
 	return vitk_attention_generic(a, true, dtype, (hipStream_t)stream);
+}
+
+extern "C" int vitk_attention_bwd(const void* dout, const void* q, const void* k, const void* v, const void* out, const float* lse, void* dq,
+	void* dk, void* dv, int64_t B, int64_t n_head, int64_t Sq, int64_t Skv, int64_t dh, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
+	int64_t lddq, int64_t lddk, int64_t lddv, float scale, int dtype, void* stream) {
+	return vitk_attention_bwd_dropout(dout, q, k, v, out, lse, dq, dk, dv, B, n_head, Sq, Skv, dh, ldq, ldk, ldv, ldo, lddq, lddk, lddv, scale, 0.f, 0, dtype,
+		stream);
 }

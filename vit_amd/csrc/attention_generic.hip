@@ -37,6 +37,8 @@ __global__ __launch_bounds__(64) void attn_fwd_generic_kernel(AttnArgs a) {
 		o[d] = 0.f;
 	}
 	float m = -INFINITY, l = 0.f;
+	const bool drop = a.drop_thr16 != 0;
+	const uint32_t rk = attn_row_key(attn_head_key(a, b * a.n_head + h), qi);
 	for (int k0 = 0; k0 < a.Skv; k0 += TK) {
 		__syncthreads();
 		stage_rows<T, DH>(Ks, kb, a.ldk, k0, a.Skv, dh);
@@ -62,8 +64,10 @@ __global__ __launch_bounds__(64) void attn_fwd_generic_kernel(AttnArgs a) {
 		for (int j = 0; j < TK; ++j) {
 			const float p = __expf(s[j] - mnew);  // exp(-inf) = 0 for masked keys
 			l += p;
+			// dropout leaves the softmax normaliser alone and removes / rescales terms of the P V sum
+			const float pv = drop ? p * attn_keep(attn_pair_bits(rk, (k0 + j) >> 1), k0 + j, a.drop_thr16, a.drop_scale) : p;
 #pragma unroll
-			for (int d = 0; d < DH; ++d) o[d] += p * Vs[j][d];
+			for (int d = 0; d < DH; ++d) o[d] += pv * Vs[j][d];
 		}
 		m = mnew;
 	}
@@ -105,6 +109,8 @@ __global__ __launch_bounds__(64) void attn_bwd_dq_kernel(AttnArgs a) {
 	if (valid)
 		for (int d = 0; d < dh; ++d) delta += to_f32<T>(gb[(int64_t)qi * a.ldo + d]) * to_f32<T>(ob[(int64_t)qi * a.ldo + d]);
 	const float lse = valid ? a.lse[((int64_t)b * a.n_head + h) * a.Sq + qi] : 0.f;
+	const bool drop = a.drop_thr16 != 0;
+	const uint32_t rk = attn_row_key(attn_head_key(a, b * a.n_head + h), qi);
 	float dq[DH];
 #pragma unroll
 	for (int d = 0; d < DH; ++d) dq[d] = 0.f;
@@ -122,6 +128,7 @@ __global__ __launch_bounds__(64) void attn_bwd_dq_kernel(AttnArgs a) {
 				dp += Gs[lane][d] * Vs[j][d];
 			}
 			const float p = __expf(s * a.scale - lse);
+			if (drop) dp *= attn_keep(attn_pair_bits(rk, (k0 + j) >> 1), k0 + j, a.drop_thr16, a.drop_scale);
 			const float ds = p * (dp - delta) * a.scale;
 #pragma unroll
 			for (int d = 0; d < DH; ++d) dq[d] += ds * Ks[j][d];
@@ -143,6 +150,8 @@ __global__ __launch_bounds__(64) void attn_bwd_dkv_kernel(AttnArgs a) {
 	__shared__ float Ks[64][DH + 1];
 	__shared__ float Vs[64][DH + 1];
 	__shared__ float Ls[TK], Ds[TK];
+	__shared__ uint32_t Rk[TK];
+	const bool drop = a.drop_thr16 != 0;
 	const int b = blockIdx.z, h = blockIdx.y;
 	const int lane = threadIdx.x;
 	const int kbase = blockIdx.x * 64;
@@ -179,6 +188,7 @@ __global__ __launch_bounds__(64) void attn_bwd_dkv_kernel(AttnArgs a) {
 			}
 			Ls[lane] = lse;
 			Ds[lane] = delta;
+			Rk[lane] = attn_row_key(attn_head_key(a, b * a.n_head + h), qi);
 		}
 		__syncthreads();
 		const int nq = min(TK, a.Sq - q0);
@@ -190,10 +200,12 @@ __global__ __launch_bounds__(64) void attn_bwd_dkv_kernel(AttnArgs a) {
 				dp += Gs[j][d] * Vs[lane][d];
 			}
 			const float p = valid ? __expf(s * a.scale - Ls[j]) : 0.f;
-			const float ds = p * (dp - Ds[j]) * a.scale;
+			const float keep = drop ? attn_keep(attn_pair_bits(Rk[j], ki >> 1), ki, a.drop_thr16, a.drop_scale) : 1.f;
+			const float ds = p * (dp * keep - Ds[j]) * a.scale;
+			const float pv = p * keep;
 #pragma unroll
 			for (int d = 0; d < DH; ++d) {
-				dv[d] += p * Gs[j][d];
+				dv[d] += pv * Gs[j][d];
 				dk[d] += ds * Qs[j][d];
 			}
 		}

@@ -80,7 +80,7 @@ __device__ __forceinline__ float group_sum(float v) {
 // ---------------------------------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------------------------------
-template <int KT2>  // keys padded to 32 * KT2
+template <int KT2, bool DROP>  // keys padded to 32 * KT2; DROP: attention-probability dropout
 __global__ __launch_bounds__(1024) void attn_fwd_mfma_kernel(AttnArgs a) {
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 	char* Ks = smem;
@@ -130,6 +130,19 @@ __global__ __launch_bounds__(1024) void attn_fwd_mfma_kernel(AttnArgs a) {
 				l += p;
 			}
 		l = group_sum(l);
+		if constexpr (DROP) {
+			// the normaliser l is that of the full softmax; dropped probabilities leave the P V product only
+			const uint32_t rk = attn_row_key(attn_head_key(a, blockIdx.x), q);
+#pragma unroll
+			for (int t = 0; t < 2 * KT2; ++t) {
+				const int k0 = 16 * t + 4 * g;
+				const uint32_t b0 = attn_pair_bits(rk, k0 >> 1), b1 = attn_pair_bits(rk, (k0 >> 1) + 1);
+				st[t][0] *= attn_keep(b0, 0, a.drop_thr16, 1.f);
+				st[t][1] *= attn_keep(b0, 1, a.drop_thr16, 1.f);
+				st[t][2] *= attn_keep(b1, 0, a.drop_thr16, 1.f);
+				st[t][3] *= attn_keep(b1, 1, a.drop_thr16, 1.f);
+			}
+		}
 		f32x4 o[4];
 #pragma unroll
 		for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -141,7 +154,7 @@ __global__ __launch_bounds__(1024) void attn_fwd_mfma_kernel(AttnArgs a) {
 			__builtin_amdgcn_sched_barrier(0);
 		}
 		if (q < a.Sq) {
-			const float inv = 1.f / l;
+			const float inv = (DROP ? a.drop_scale : 1.f) / l;
 			bf16_t* op = reinterpret_cast<bf16_t*>(a.out_w) + ((int64_t)b * a.Sq + q) * a.ldo + h * DH + 4 * g;
 #pragma unroll
 			for (int dt = 0; dt < 4; ++dt) {
@@ -158,7 +171,7 @@ __global__ __launch_bounds__(1024) void attn_fwd_mfma_kernel(AttnArgs a) {
 // ---------------------------------------------------------------------------------------------------------------
 // backward: dQ (query on the lane)
 // ---------------------------------------------------------------------------------------------------------------
-template <int KT2>
+template <int KT2, bool DROP>
 __global__ __launch_bounds__(1024) void attn_bwd_dq_mfma_kernel(AttnArgs a) {
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 	char* Ks = smem;
@@ -188,6 +201,7 @@ __global__ __launch_bounds__(1024) void attn_bwd_dq_mfma_kernel(AttnArgs a) {
 		for (int j = 0; j < 8; ++j) delta += (float)gf0[j] * (float)of0[j] + (float)gf1[j] * (float)of1[j];
 		delta = group_sum(delta);
 		const float lse2 = a.lse[((int64_t)b * a.n_head + h) * a.Sq + qc] * LOG2E;
+		const uint32_t rk = DROP ? attn_row_key(attn_head_key(a, blockIdx.x), q) : 0u;
 		f32x4 dq[4];
 #pragma unroll
 		for (int dt = 0; dt < 4; ++dt) dq[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -202,6 +216,15 @@ __global__ __launch_bounds__(1024) void attn_bwd_dq_mfma_kernel(AttnArgs a) {
 				s = mfma16(row_frag(Ks, 16 * t, 1, lane), qf1, s);
 				dp = mfma16(row_frag(Vs, 16 * t, 0, lane), gf0, dp);
 				dp = mfma16(row_frag(Vs, 16 * t, 1, lane), gf1, dp);
+				if constexpr (DROP) {
+					// out = (P o M) V with M in {0, 1/(1-p)}: dP = M o (dO V^T); delta = rowsum(dO o out) as without dropout
+					const int k0 = 16 * t + 4 * g;
+					const uint32_t b0 = attn_pair_bits(rk, k0 >> 1), b1 = attn_pair_bits(rk, (k0 >> 1) + 1);
+					dp[0] *= attn_keep(b0, 0, a.drop_thr16, a.drop_scale);
+					dp[1] *= attn_keep(b0, 1, a.drop_thr16, a.drop_scale);
+					dp[2] *= attn_keep(b1, 0, a.drop_thr16, a.drop_scale);
+					dp[3] *= attn_keep(b1, 1, a.drop_thr16, a.drop_scale);
+				}
 #pragma unroll
 				for (int r = 0; r < 4; ++r) {
 					const float p = __builtin_amdgcn_exp2f(s[r] * c - lse2);
@@ -233,7 +256,7 @@ __global__ __launch_bounds__(1024) void attn_bwd_dq_mfma_kernel(AttnArgs a) {
 // ---------------------------------------------------------------------------------------------------------------
 // backward: dK, dV (key on the lane)
 // ---------------------------------------------------------------------------------------------------------------
-template <int QT2>  // queries padded to 32 * QT2
+template <int QT2, bool DROP>  // queries padded to 32 * QT2
 __global__ __launch_bounds__(1024) void attn_bwd_dkv_mfma_kernel(AttnArgs a) {
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 	constexpr int QP = QT2 * 32;
@@ -241,9 +264,14 @@ __global__ __launch_bounds__(1024) void attn_bwd_dkv_mfma_kernel(AttnArgs a) {
 	char* Gs = smem + QP * 128;
 	float* lse_s = reinterpret_cast<float*>(smem + 2 * QP * 128);
 	float* del_s = lse_s + QP;
+	uint32_t* rk_s = reinterpret_cast<uint32_t*>(del_s + QP);  // dropout: mask key of every query row
 	const int b = blockIdx.x / a.n_head, h = blockIdx.x % a.n_head;
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
 	const int g = lane >> 4;
+	if constexpr (DROP) {
+		const uint32_t hk = attn_head_key(a, blockIdx.x);
+		for (int r = threadIdx.x; r < QP; r += blockDim.x) rk_s[r] = attn_row_key(hk, r);
+	}
 	const bf16_t* qb = reinterpret_cast<const bf16_t*>(a.q) + (int64_t)b * a.Sq * a.ldq + h * DH;
 	const bf16_t* gb = reinterpret_cast<const bf16_t*>(a.dout) + (int64_t)b * a.Sq * a.ldo + h * DH;
 	const bf16_t* ob = reinterpret_cast<const bf16_t*>(a.out) + (int64_t)b * a.Sq * a.ldo + h * DH;
@@ -300,12 +328,20 @@ __global__ __launch_bounds__(1024) void attn_bwd_dkv_mfma_kernel(AttnArgs a) {
 				dp = mfma16(row_frag(Gs, 16 * t, 1, lane), vf1, dp);
 				const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_s + 16 * t + 4 * g);
 				const f32x4 d4 = *reinterpret_cast<const f32x4*>(del_s + 16 * t + 4 * g);
+				float keep[4] = {1.f, 1.f, 1.f, 1.f};
+				if constexpr (DROP) {
+					const uint4 rk4 = *reinterpret_cast<const uint4*>(rk_s + 16 * t + 4 * g);
+					keep[0] = attn_keep(attn_pair_bits(rk4.x, key >> 1), key, a.drop_thr16, a.drop_scale);
+					keep[1] = attn_keep(attn_pair_bits(rk4.y, key >> 1), key, a.drop_thr16, a.drop_scale);
+					keep[2] = attn_keep(attn_pair_bits(rk4.z, key >> 1), key, a.drop_thr16, a.drop_scale);
+					keep[3] = attn_keep(attn_pair_bits(rk4.w, key >> 1), key, a.drop_thr16, a.drop_scale);
+				}
 #pragma unroll
 				for (int r = 0; r < 4; ++r) {
 					float pr = __builtin_amdgcn_exp2f(s[r] * c - l4[r]);
 					if (!key_ok) pr = 0.f;
-					p[hf][r] = pr;
-					ds[hf][r] = pr * (dp[r] - d4[r]) * a.scale;
+					p[hf][r] = DROP ? pr * keep[r] : pr;  // dV = (P o M)^T dO
+					ds[hf][r] = pr * ((DROP ? dp[r] * keep[r] : dp[r]) - d4[r]) * a.scale;
 				}
 			}
 			const bf16x8 pf = pack8(p[0], p[1]);
@@ -334,59 +370,61 @@ __global__ __launch_bounds__(1024) void attn_bwd_dkv_mfma_kernel(AttnArgs a) {
 	}
 }
 
-template <int T2>
+template <int T2, bool DROP>
 int launch_fwd(const AttnArgs& a, hipStream_t st) {
 	const int nw = std::min(16, (a.Sq + 15) / 16);
 	const size_t lds = (size_t)2 * T2 * 32 * 128;
 	static bool attr = false;
 	if (!attr) {
-		hipError_t e = hipFuncSetAttribute((const void*)attn_fwd_mfma_kernel<T2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+		hipError_t e = hipFuncSetAttribute((const void*)attn_fwd_mfma_kernel<T2, DROP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 		if (e != hipSuccess) return VITK_ERR_HIP - (int)e;
 		attr = true;
 	}
-	hipLaunchKernelGGL((attn_fwd_mfma_kernel<T2>), dim3((unsigned)(a.B * a.n_head)), dim3(64 * nw), lds, st, a);
+	hipLaunchKernelGGL((attn_fwd_mfma_kernel<T2, DROP>), dim3((unsigned)(a.B * a.n_head)), dim3(64 * nw), lds, st, a);
 	VITK_CHECK_LAUNCH();
 	return VITK_OK;
 }
-template <int T2>
+template <int T2, bool DROP>
 int launch_dq(const AttnArgs& a, hipStream_t st) {
 	const int nw = std::min(16, (a.Sq + 15) / 16);
 	const size_t lds = (size_t)2 * T2 * 32 * 128;
 	static bool attr = false;
 	if (!attr) {
-		hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_dq_mfma_kernel<T2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+		hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_dq_mfma_kernel<T2, DROP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 		if (e != hipSuccess) return VITK_ERR_HIP - (int)e;
 		attr = true;
 	}
-	hipLaunchKernelGGL((attn_bwd_dq_mfma_kernel<T2>), dim3((unsigned)(a.B * a.n_head)), dim3(64 * nw), lds, st, a);
+	hipLaunchKernelGGL((attn_bwd_dq_mfma_kernel<T2, DROP>), dim3((unsigned)(a.B * a.n_head)), dim3(64 * nw), lds, st, a);
 	VITK_CHECK_LAUNCH();
 	return VITK_OK;
 }
-template <int T2>
+template <int T2, bool DROP>
 int launch_dkv(const AttnArgs& a, hipStream_t st) {
 	const int nw = std::min(16, (a.Skv + 15) / 16);
-	const size_t lds = (size_t)2 * T2 * 32 * 128 + (size_t)2 * T2 * 32 * sizeof(float);
+	const size_t lds = (size_t)2 * T2 * 32 * 128 + (size_t)3 * T2 * 32 * sizeof(float);
 	static bool attr = false;
 	if (!attr) {
-		hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_dkv_mfma_kernel<T2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+		hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_dkv_mfma_kernel<T2, DROP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 		if (e != hipSuccess) return VITK_ERR_HIP - (int)e;
 		attr = true;
 	}
-	hipLaunchKernelGGL((attn_bwd_dkv_mfma_kernel<T2>), dim3((unsigned)(a.B * a.n_head)), dim3(64 * nw), lds, st, a);
+	hipLaunchKernelGGL((attn_bwd_dkv_mfma_kernel<T2, DROP>), dim3((unsigned)(a.B * a.n_head)), dim3(64 * nw), lds, st, a);
 	VITK_CHECK_LAUNCH();
 	return VITK_OK;
 }
 
-#define DISPATCH_T2(n, FN)                   \
-	switch (n) {                             \
-		case 1: return FN<1>(a, st);         \
-		case 2: return FN<2>(a, st);         \
-		case 3: return FN<3>(a, st);         \
-		case 4: return FN<4>(a, st);         \
-		case 5: return FN<5>(a, st);         \
-		case 6: return FN<6>(a, st);         \
-		case 7: return FN<7>(a, st);         \
-		case 8: return FN<8>(a, st);         \
+#define DISPATCH_CASE(n, FN) \
+	case n: return a.drop_thr16 != 0 ? FN<n, true>(a, st) : FN<n, false>(a, st);
+#define DISPATCH_T2(n, FN)                    \
+	switch (n) {                              \
+		DISPATCH_CASE(1, FN)                  \
+		DISPATCH_CASE(2, FN)                  \
+		DISPATCH_CASE(3, FN)                  \
+		DISPATCH_CASE(4, FN)                  \
+		DISPATCH_CASE(5, FN)                  \
+		DISPATCH_CASE(6, FN)                  \
+		DISPATCH_CASE(7, FN)                  \
+		DISPATCH_CASE(8, FN)                  \
 		default: return VITK_ERR_UNSUPPORTED; \
 	}
 

@@ -30,9 +30,9 @@ class MHA(nn.Module):
 			raise NotImplementedError("use_qk_norm=True is not supported (the reference's QKNorm cannot be constructed by its MHA either)")
 
 	def forward(self, query):
-		if self.dropout.active():
-			raise NotImplementedError("attention-probability dropout (dropout_p > 0 in training) is not implemented; use dropout=0.0 or eval()")
-		return ops.MHAFn.apply(query, self.qkv_proj.weight, self.out_proj.weight, self.out_proj.bias, self.n_head)
+		# dropout_p=self.dropout.p if self.training else 0.0 (layers/attention.py:41 there)
+		drop = (self.dropout.p, ops.next_dropout_seed()) if self.dropout.active() else (0.0, 0)
+		return ops.MHAFn.apply(query, self.qkv_proj.weight, self.out_proj.weight, self.out_proj.bias, self.n_head, drop)
 
 
 class ConvAttention(nn.Module):
@@ -51,11 +51,11 @@ class ConvAttention(nn.Module):
 		self.kernel_size, self.qkv_stride, self.padding = kernel_size, qkv_stride, padding
 
 	def forward(self, x, h, w):
-		if self.dropout.active():
-			raise NotImplementedError("attention-probability dropout (dropout_p > 0 in training) is not implemented; use dropout=0.0 or eval()")
+		# dropout_p=self.dropout.p if self.training else 0.0 (layers/attention.py:86 there)
+		drop = (self.dropout.p, ops.next_dropout_seed()) if self.dropout.active() else (0.0, 0)
 		return ops.ConvAttentionFn.apply(x, self.q_proj.weight, self.q_proj.bias, self.k_proj.weight, self.k_proj.bias,
 			self.v_proj.weight, self.v_proj.bias, self.conv_proj_k.weight, self.conv_proj_v.weight,
-			self.out_proj.weight, self.out_proj.bias, (h, w, self.n_head, self.kernel_size, self.qkv_stride, self.padding))
+			self.out_proj.weight, self.out_proj.bias, (h, w, self.n_head, self.kernel_size, self.qkv_stride, self.padding, drop))
 
 
 class QuadrangleAttention(nn.Module):

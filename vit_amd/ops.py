@@ -345,22 +345,24 @@ def norm_bwd(dy, x, weight, mean, rstd, kind, unit_offset=True, dres=None, dw_ou
 	return dx, dw, None
 
 
-def attention_fwd(q, k, v, B, n_head, Sq, Skv, dh, scale=0.0):
-	"""q: [B*Sq, >=h*dh] view, k/v: [B*Skv, ...] views (unit inner stride).  Returns (out [B*Sq, h*dh], lse [B,h,Sq])."""
+def attention_fwd(q, k, v, B, n_head, Sq, Skv, dh, scale=0.0, drop=(0.0, 0)):
+	"""q: [B*Sq, >=h*dh] view, k/v: [B*Skv, ...] views (unit inner stride).  Returns (out [B*Sq, h*dh], lse [B,h,Sq]).
+	drop = (dropout_p, seed): dropout on the attention probabilities (layers/attention.py:41,86); the backward must be
+	given the same pair."""
 	out = torch.empty((B * Sq, n_head * dh), dtype=q.dtype, device=q.device)
 	lse = torch.empty((B, n_head, Sq), dtype=torch.float32, device=q.device)
 	assert q.stride(1) == 1 and k.stride(1) == 1 and v.stride(1) == 1
-	L.check(L.load().vitk_attention_fwd(L.ptr(q), L.ptr(k), L.ptr(v), L.ptr(out), L.ptr(lse), B, n_head, Sq, Skv, dh,
-		q.stride(0), k.stride(0), v.stride(0), out.stride(0), scale, L.dtype_code(q.dtype), L.stream()))
+	L.check(L.load().vitk_attention_fwd_dropout(L.ptr(q), L.ptr(k), L.ptr(v), L.ptr(out), L.ptr(lse), B, n_head, Sq, Skv, dh,
+		q.stride(0), k.stride(0), v.stride(0), out.stride(0), scale, float(drop[0]), int(drop[1]), L.dtype_code(q.dtype), L.stream()))
 	return out, lse
 
 
-def attention_bwd(dout, q, k, v, out, lse, dq, dk, dv, B, n_head, Sq, Skv, dh, scale=0.0):
+def attention_bwd(dout, q, k, v, out, lse, dq, dk, dv, B, n_head, Sq, Skv, dh, scale=0.0, drop=(0.0, 0)):
 	"""Writes dq/dk/dv (views with unit inner stride, e.g. column slices of one [rows, 3d] buffer)."""
 	assert dout.stride(1) == 1 and dout.stride(0) == out.stride(0)
-	L.check(L.load().vitk_attention_bwd(L.ptr(dout), L.ptr(q), L.ptr(k), L.ptr(v), L.ptr(out), L.ptr(lse), L.ptr(dq), L.ptr(dk), L.ptr(dv),
+	L.check(L.load().vitk_attention_bwd_dropout(L.ptr(dout), L.ptr(q), L.ptr(k), L.ptr(v), L.ptr(out), L.ptr(lse), L.ptr(dq), L.ptr(dk), L.ptr(dv),
 		B, n_head, Sq, Skv, dh, q.stride(0), k.stride(0), v.stride(0), out.stride(0), dq.stride(0), dk.stride(0), dv.stride(0),
-		scale, L.dtype_code(q.dtype), L.stream()))
+		scale, float(drop[0]), int(drop[1]), L.dtype_code(q.dtype), L.stream()))
 
 
 def gated_act_fwd(u, F, act):
@@ -513,24 +515,24 @@ class FeedForwardFn(torch.autograd.Function):
 		return dx, grad_as(dw1, w1), grad_as(db1, b1), grad_as(dw2, w2), grad_as(db2, b2), None, None
 
 
-def _mha_forward(x2, wqkv, wo, bo, B, S, n_head, residual=None, gamma=None):
+def _mha_forward(x2, wqkv, wo, bo, B, S, n_head, residual=None, gamma=None, drop=(0.0, 0)):
 	"""qkv projection -> attention -> out projection (layers/attention.py:27-48).  Returns (y, qkv, o, lse)."""
 	d = x2.shape[1]
 	dh = d // n_head
 	qkv = linear_fwd(x2, wqkv)
-	o, lse = attention_fwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], B, n_head, S, S, dh)
+	o, lse = attention_fwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], B, n_head, S, S, dh, drop=drop)
 	y = linear_fwd(o, wo, bo, residual=residual, gamma=gamma)
 	return y, qkv, o, lse
 
 
-def _mha_backward(dy2, x2, qkv, o, lse, wqkv, wo, B, S, n_head, need_dx=True, outs=(None, None, None)):
+def _mha_backward(dy2, x2, qkv, o, lse, wqkv, wo, B, S, n_head, need_dx=True, outs=(None, None, None), drop=(0.0, 0)):
 	"""Returns (dx, dwqkv, dwo, dbo).  outs = buffers to accumulate (dwqkv, dwo, dbo) into (gradient sinks) or None."""
 	d = x2.shape[1]
 	dh = d // n_head
 	dwo, dbo = linear_wgrad(dy2, o, bias_grad=True, dw_out=outs[1], db_out=outs[2])
 	do = linear_dgrad(dy2, wo)
 	dqkv = torch.empty_like(qkv)
-	attention_bwd(do, qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], o, lse, dqkv[:, :d], dqkv[:, d:2 * d], dqkv[:, 2 * d:], B, n_head, S, S, dh)
+	attention_bwd(do, qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], o, lse, dqkv[:, :d], dqkv[:, d:2 * d], dqkv[:, 2 * d:], B, n_head, S, S, dh, drop=drop)
 	dwqkv = linear_wgrad(dqkv, x2, dw_out=outs[0])
 	dx = linear_dgrad(dqkv, wqkv) if need_dx else None
 	return dx, dwqkv, dwo, dbo
@@ -538,27 +540,27 @@ def _mha_backward(dy2, x2, qkv, o, lse, wqkv, wo, B, S, n_head, need_dx=True, ou
 
 class MHAFn(torch.autograd.Function):
 	@staticmethod
-	def forward(ctx, x, wqkv, wo, bo, n_head):
+	def forward(ctx, x, wqkv, wo, bo, n_head, drop=(0.0, 0)):
 		L.require_gpu(x, wqkv)
 		dt = compute_dtype(x)
 		B, S, d = x.shape
 		x2 = _flat(cast(x, dt))
-		y, qkv, o, lse = _mha_forward(x2, weight_as(wqkv, dt), weight_as(wo, dt), f32(bo), B, S, n_head)
+		y, qkv, o, lse = _mha_forward(x2, weight_as(wqkv, dt), weight_as(wo, dt), f32(bo), B, S, n_head, drop=drop)
 		ctx.save_for_backward(x2, qkv, o, lse, wqkv, wo)
-		ctx.meta = (x.shape, x.dtype, bo, n_head, dt)
+		ctx.meta = (x.shape, x.dtype, bo, n_head, dt, drop)
 		return y.reshape(B, S, d)
 
 	@staticmethod
 	def backward(ctx, dy):
 		x2, qkv, o, lse, wqkv, wo = ctx.saved_tensors
-		(B, S, d), xdtype, bo, n_head, dt = ctx.meta
+		(B, S, d), xdtype, bo, n_head, dt, drop = ctx.meta
 		dy2 = _flat(cast(dy, dt))
-		dx, dwqkv, dwo, dbo = _mha_backward(dy2, x2, qkv, o, lse, weight_as(wqkv, dt), weight_as(wo, dt), B, S, n_head, ctx.needs_input_grad[0])
+		dx, dwqkv, dwo, dbo = _mha_backward(dy2, x2, qkv, o, lse, weight_as(wqkv, dt), weight_as(wo, dt), B, S, n_head, ctx.needs_input_grad[0], drop=drop)
 		if dx is not None:
 			dx = dx.reshape(B, S, d)
 			if dx.dtype != xdtype:
 				dx = cast(dx, xdtype)
-		return dx, grad_as(dwqkv, wqkv), grad_as(dwo, wo), grad_as(dbo, bo), None
+		return dx, grad_as(dwqkv, wqkv), grad_as(dwo, wo), grad_as(dbo, bo), None, None
 
 
 class ViTBlockFn(torch.autograd.Function):
@@ -833,12 +835,16 @@ class DropoutFn(torch.autograd.Function):
 		return dx, None, None
 
 
-def dropout(x, p):
-	"""Training-mode inverted dropout.  The seed comes from torch's CPU generator (so torch.manual_seed makes runs
-	repeatable) plus a per-call counter; no device synchronisation."""
+def next_dropout_seed():
+	"""Seed of the next dropout mask: torch's CPU generator seed (so torch.manual_seed makes runs repeatable) mixed with
+	a per-call counter; no device synchronisation."""
 	_dropout_calls[0] += 1
-	seed = (torch.initial_seed() * 0x9E3779B1 + _dropout_calls[0] * 0x85EBCA77) & 0xFFFFFFFFFFFFFFFF
-	return DropoutFn.apply(x, float(p), seed)
+	return (torch.initial_seed() * 0x9E3779B1 + _dropout_calls[0] * 0x85EBCA77) & 0xFFFFFFFFFFFFFFFF
+
+
+def dropout(x, p):
+	"""Training-mode inverted dropout."""
+	return DropoutFn.apply(x, float(p), next_dropout_seed())
 
 
 # --------------------------------------------------------------------------------------------------
@@ -945,7 +951,8 @@ class ConvAttentionFn(torch.autograd.Function):
 
 	@staticmethod
 	def forward(ctx, x, wq, bq, wk, bk, wv, bv, ck, cv, wo, bo, cfg):
-		H, W, n_head, ks, stride, pad = cfg
+		H, W, n_head, ks, stride, pad = cfg[:6]
+		drop = cfg[6] if len(cfg) > 6 else (0.0, 0)
 		L.require_gpu(x, wq)
 		dt = compute_dtype(x)
 		Bn, S, C = x.shape
@@ -958,7 +965,7 @@ class ConvAttentionFn(torch.autograd.Function):
 		ckc, cvc = weight_as(ck, dt), weight_as(cv, dt)
 		k1, Skv = dwconv_fwd(k0, ckc, Bn, H, W, C, ks, stride, pad)
 		v1, _ = dwconv_fwd(v0, cvc, Bn, H, W, C, ks, stride, pad)
-		o, lse = attention_fwd(q, k1, v1, Bn, n_head, S, Skv, dh)
+		o, lse = attention_fwd(q, k1, v1, Bn, n_head, S, Skv, dh, drop=drop)
 		y = linear_fwd(o, weight_as(wo, dt), f32(bo))
 		ctx.save_for_backward(x2, q, k0, v0, k1, v1, o, lse, wq, wk, wv, ck, cv, wo)
 		ctx.meta = (x.shape, x.dtype, (bq, bk, bv, bo), cfg, dt, Skv)
@@ -968,13 +975,14 @@ class ConvAttentionFn(torch.autograd.Function):
 	def backward(ctx, dy):
 		x2, q, k0, v0, k1, v1, o, lse, wq, wk, wv, ck, cv, wo = ctx.saved_tensors
 		(Bn, S, C), xdtype, (bq, bk, bv, bo), cfg, dt, Skv = ctx.meta
-		H, W, n_head, ks, stride, pad = cfg
+		H, W, n_head, ks, stride, pad = cfg[:6]
+		drop = cfg[6] if len(cfg) > 6 else (0.0, 0)
 		dh = C // n_head
 		dy2 = _flat(cast(dy, dt))
 		dwo, dbo = linear_wgrad(dy2, o, bias_grad=True)
 		do = linear_dgrad(dy2, weight_as(wo, dt))
 		dq, dk1, dv1 = torch.empty_like(q), torch.empty_like(k1), torch.empty_like(v1)
-		attention_bwd(do, q, k1, v1, o, lse, dq, dk1, dv1, Bn, n_head, S, Skv, dh)
+		attention_bwd(do, q, k1, v1, o, lse, dq, dk1, dv1, Bn, n_head, S, Skv, dh, drop=drop)
 		dk0, dck = dwconv_bwd(dk1, k0, weight_as(ck, dt), Bn, H, W, C, ks, stride, pad)
 		dv0, dcv = dwconv_bwd(dv1, v0, weight_as(cv, dt), Bn, H, W, C, ks, stride, pad)
 		dwq, dbq = linear_wgrad(dq, x2, bias_grad=True)
