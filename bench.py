@@ -37,7 +37,7 @@ def train_flops_per_image(c):
 	return 3.0 * fwd
 
 
-def make_config(c):
+def make_config(c, dropout=0.0):
 	from vit_amd.layers import MHA
 
 	class Cfg:
@@ -49,6 +49,7 @@ def make_config(c):
 		dropout = 0.0
 	for k in ("d_model", "n_head", "n_block", "n_patch", "d_ff", "out_d", "chw"):
 		setattr(Cfg, k, c[k])
+	Cfg.dropout = dropout
 	return Cfg()
 
 
@@ -85,6 +86,7 @@ def main():
 	ap.add_argument("--graph", action="store_true", help="capture the training step into a HIP graph and replay it (single GPU)")
 	ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the config's)")
 	ap.add_argument("--config", default="vit_b16", choices=sorted(CONFIGS))
+	ap.add_argument("--dropout", type=float, default=0.0, help="config.dropout (attention-probability, branch and feed-forward dropouts)")
 	ap.add_argument("--no-cpu-baseline", action="store_true")
 	ap.add_argument("--no-kernel-timing", action="store_true")
 	args = ap.parse_args()
@@ -106,7 +108,7 @@ def main():
 	c = CONFIGS[args.config]
 	batch = args.batch or c["batch"]
 	torch.manual_seed(0)
-	model = ViT(make_config(c)).to(dev)
+	model = ViT(make_config(c, args.dropout)).to(dev)
 	trainer = dp.Trainer(model, lr=1e-3, weight_decay=0.05)
 	g = torch.Generator(device="cpu").manual_seed(1234 + rank)
 	x = torch.randn(batch, *c["chw"], generator=g).to(dev)
@@ -165,7 +167,7 @@ def main():
 			"dtype": "bf16", "data": "synthetic",
 			"config": {"workload": f"{args.config}: ViT d{c['d_model']}/h{c['n_head']}/L{c['n_block']}/ff{c['d_ff']} patch{c['chw'][1] // c['n_patch']} at {c['chw'][1]}x{c['chw'][2]}, "
 				f"{c['n_patch'] ** 2 + 1} tokens, fwd+CE+bwd+AdamW, fp32 master weights, bf16 activations", "global_batch": batch * world, "per_gpu_batch": batch,
-				"parallelism": f"dp{world}", "hip_graph": bool(args.graph)},
+				"parallelism": f"dp{world}", "hip_graph": bool(args.graph), "dropout": args.dropout},
 			"train_gflop_per_image": round(flops_img / 1e9, 3),
 			"mfma_util_pct": round(100.0 * value * flops_img / (world * PEAK_BF16_TFLOPS * 1e12), 2),
 			"final_loss": round(final_loss, 4),

@@ -204,6 +204,12 @@ int vitk_act_bwd(const void* dy, const void* x, void* dx, int64_t n, int act, in
  * The random stream differs from torch's Philox stream, so training-mode dropout matches the
  * reference in distribution only. */
 int vitk_dropout(const void* x, void* y, int64_t n, float p, uint64_t seed, int dtype, void* stream);
+/* y = res + dropout(dropout(x, p1, seed1), p2, seed2): the branch dropout(s) and the residual add of a block in one
+ * pass (layers/vit.py:43-47 and 51-55; the feed-forward branch passes through FeedForward.dropout2,
+ * layers/transformers.py:55, and ViTBlock.ff_dropout back to back).  res nullable (then y is the dropped x: the
+ * backward of the same expression), p2 = 0 applies one mask only.  Masks as in vitk_dropout. */
+int vitk_dropout_add(const void* x, const void* res, void* y, int64_t n, float p1, uint64_t seed1, float p2, uint64_t seed2,
+	int dtype, void* stream);
 /* y = res + gamma[col] * x (gamma nullable); rows x d.  layers/vit.py:44-47,52-55 when not fused in a GEMM */
 int vitk_scale_residual(const void* x, const void* res, const float* gamma, void* y, int64_t rows, int64_t d, int dtype, void* stream);
 /* LayerScale backward: dbranch = gamma * dy ; dgamma[col] += sum_rows dy * branch */

@@ -196,6 +196,44 @@ def test_reference_config_trains(gpu):
 	assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in model.parameters())
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("act", ["gelu", "swiglu"])
+def test_fused_block_with_dropout_matches_composition(gpu, dtype, act):
+	"""With dropout active the block still runs as one fused node; given the same seeds (both paths draw them in the
+	order attention, attention branch, dropout1, dropout2, feed-forward branch) it must reproduce the module-by-module
+	composition: same output, same gradients."""
+	from vit_amd import ops
+	from vit_amd.layers import MHA, ViTBlock
+
+	class Cfg:
+		d_model = 128; n_head = 2; d_ff = 256; dropout = 0.3; activation = act; norm = nn.LayerNorm
+		use_layer_scale = False; use_qk_norm = False; attention = MHA
+	torch.manual_seed(0)
+	blk = ViTBlock(Cfg()).to(gpu).train()
+	x = torch.randn(3, 40, 128, device=gpu).to(dtype)
+	gy = torch.randn(3, 40, 128, device=gpu).to(dtype)
+	results = []
+	for fused in (True, False):
+		if not fused:
+			blk._fusable = lambda: False
+		torch.manual_seed(11)
+		ops._dropout_calls[0] = 0
+		xi = x.clone().requires_grad_()
+		blk.zero_grad()
+		y, _ = blk(xi)
+		y.backward(gy)
+		results.append((y.detach(), xi.grad, {k: p.grad.clone() for k, p in blk.named_parameters()}))
+	(y1, dx1, g1), (y2, dx2, g2) = results
+	tol = 1e-5 if dtype == torch.float32 else 2e-2
+	assert relerr(y1, y2) < tol and relerr(dx1, dx2) < tol
+	for k in g1:
+		assert relerr(g1[k], g2[k]) < (1e-4 if dtype == torch.float32 else 4e-2), k
+	# and dropout really was on: the eval-mode output differs
+	blk.eval()
+	y_eval, _ = blk(x)
+	assert relerr(y1, y_eval) > 1e-2
+
+
 def make_cvt(c, gpu):
 	from vit_amd.layers import RMSNorm
 	from vit_amd.models import CvT

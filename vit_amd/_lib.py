@@ -60,6 +60,7 @@ SIGNATURES = {
 	"vitk_transpose": [P, P, I64, I64, I64, I64, I, P],
 	"vitk_transpose_batched": [P, P, I64, I, P],
 	"vitk_dropout": [P, P, I64, FL, ctypes.c_uint64, I, P],
+	"vitk_dropout_add": [P, P, P, I64, FL, ctypes.c_uint64, FL, ctypes.c_uint64, I, P],
 	"vitk_colsum": [P, P, I64, I64, I64, I, I, P],
 	"vitk_gated_act_fwd": [P, P, I64, I64, I64, I, I, P],
 	"vitk_gated_act_bwd": [P, P, P, I64, I64, I64, I, I, P],

@@ -60,6 +60,17 @@ struct DropF {
 	}
 };
 
+// y = res + x * keep1(i) * keep2(i): one or two stacked dropouts and the residual add in one pass
+struct DropAddF {
+	DropF d1, d2;
+	bool two;
+	__device__ float operator()(float a, float res, int64_t i) const {
+		float v = d1(a, 0.f, i);
+		if (two) v = d2(v, 0.f, i);
+		return res + v;
+	}
+};
+
 // ---- column sum: out[n] += sum_m x[m*ld + n] ------------------------------------------------------
 // blockDim = (CX, RY): CX lanes own VEC consecutive columns each, RY row groups stream disjoint rows with 4
 // independent 16-byte loads in flight per lane; the row groups combine through LDS and the block issues ONE float
@@ -459,6 +470,14 @@ extern "C" int vitk_dropout(const void* x, void* y, int64_t n, float p, uint64_t
 	VITK_REQUIRE(x && y, VITK_ERR_NULL);
 	VITK_REQUIRE(n >= 0 && p >= 0.f && p < 1.f, VITK_ERR_SHAPE);
 	DISPATCH_T(dtype, return (launch_map2<T, T, T>(x, nullptr, y, n, DropF{p, 1.f / (1.f - p), seed}, (hipStream_t)stream)));
+}
+
+extern "C" int vitk_dropout_add(const void* x, const void* res, void* y, int64_t n, float p1, uint64_t seed1, float p2, uint64_t seed2, int dtype,
+	void* stream) {
+	VITK_REQUIRE(x && y, VITK_ERR_NULL);
+	VITK_REQUIRE(n >= 0 && p1 >= 0.f && p1 < 1.f && p2 >= 0.f && p2 < 1.f, VITK_ERR_SHAPE);
+	const DropAddF f{DropF{p1, 1.f / (1.f - p1), seed1}, DropF{p2, 1.f / (1.f - p2), seed2}, p2 > 0.f};
+	DISPATCH_T(dtype, return (launch_map2<T, T, T>(x, res, y, n, f, (hipStream_t)stream)));
 }
 
 extern "C" int vitk_colsum(const void* x, float* out, int64_t M, int64_t N, int64_t ld, int accumulate, int dtype, void* stream) {

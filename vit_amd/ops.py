@@ -386,6 +386,13 @@ def scale_residual(x, res, gamma):
 	return y
 
 
+def dropout_add(x, res, p1, seed1, p2=0.0, seed2=0, out=None):
+	"""res + dropout(dropout(x, p1), p2) in one pass (res may be None; out may alias x)."""
+	y = torch.empty_like(x) if out is None else out
+	L.check(L.load().vitk_dropout_add(L.ptr(x), L.ptr(res), L.ptr(y), x.numel(), float(p1), int(seed1), float(p2), int(seed2), L.dtype_code(x.dtype), L.stream()))
+	return y
+
+
 def layerscale_bwd(dy, branch, gamma):
 	rows, d = dy.shape
 	dbranch = torch.empty_like(dy)
@@ -465,27 +472,34 @@ class NormFn(torch.autograd.Function):
 		return dx, grad_as(dw, weight), grad_as(db, bias) if bias is not None else None, None, None, None
 
 
-def _ffn_forward(x2, w1, b1, w2, b2, act, gated, residual=None, gamma=None):
-	"""fc_in -> act / gate*act -> fc_out (layers/transformers.py:45-57).  Returns (y, u, a)."""
+def _ffn_forward(x2, w1, b1, w2, b2, act, gated, residual=None, gamma=None, drop1=(0.0, 0)):
+	"""fc_in -> act / gate*act -> dropout1 -> fc_out (layers/transformers.py:45-57).  Returns (y, u, a) with `a` the
+	input of fc_out (after dropout1, which is applied in place)."""
 	if gated:
 		u = linear_fwd(x2, w1, b1)
 		F = w2.shape[1]
 		a = gated_act_fwd(u, F, act)
 	else:
 		a, u = linear_fwd(x2, w1, b1, act=act, save_pre=True)
+	if drop1[0] > 0.0:
+		dropout_add(a, None, drop1[0], drop1[1], out=a)
 	y = linear_fwd(a, w2, b2, residual=residual, gamma=gamma)
 	return y, u, a
 
 
-def _ffn_backward(dy2, x2, u, a, w1, w2, act, gated, need_dx=True, outs=(None, None, None, None)):
+def _ffn_backward(dy2, x2, u, a, w1, w2, act, gated, need_dx=True, outs=(None, None, None, None), drop1=(0.0, 0)):
 	"""Returns (dx, dw1, db1, dw2, db2) with float32 parameter gradients.  outs = buffers to accumulate
-	(dw1, db1, dw2, db2) into (gradient sinks) or None each."""
+	(dw1, db1, dw2, db2) into (gradient sinks) or None each.  `a` is fc_out's input (after dropout1)."""
 	dw2, db2 = linear_wgrad(dy2, a, bias_grad=True, dw_out=outs[2], db_out=outs[3])
 	if gated:
 		da = linear_dgrad(dy2, w2)
+		if drop1[0] > 0.0:
+			dropout_add(da, None, drop1[0], drop1[1], out=da)
 		du = gated_act_bwd(da, u, w2.shape[1], act)
 	else:
 		du = linear_dgrad(dy2, w2, act=act, pre=u)
+		if drop1[0] > 0.0:  # the mask and the activation derivative are both elementwise factors
+			dropout_add(du, None, drop1[0], drop1[1], out=du)
 	dw1, db1 = linear_wgrad(du, x2, bias_grad=True, dw_out=outs[0], db_out=outs[1])
 	dx = linear_dgrad(du, w1) if need_dx else None
 	return dx, dw1, db1, dw2, db2
@@ -573,21 +587,36 @@ class ViTBlockFn(torch.autograd.Function):
 	@staticmethod
 	def forward(ctx, x, n1w, n1b, wqkv, wo, bo, ls1, n2w, n2b, w1, b1, w2, b2, ls2, cfg):
 		L.require_gpu(x, wqkv)
-		kind, eps, unit_offset, n_head, act, gated = cfg
+		kind, eps, unit_offset, n_head, act, gated = cfg[:6]
+		# active dropouts of the block (None = none): {"attn": attention probabilities, "a": attention branch,
+		# "f1" / "f2": FeedForward.dropout1 / dropout2, "b": feed-forward branch}, each (p, seed); without LayerScale only
+		dr = cfg[6] if len(cfg) > 6 and cfg[6] is not None else {}
+		off = (0.0, 0)
+		d_attn, d_a, d_f1, d_f2, d_b = (dr.get(k, off) for k in ("attn", "a", "f1", "f2", "b"))
+		assert not dr or (ls1 is None and ls2 is None)
 		dt = compute_dtype(x)
 		B, S, d = x.shape
 		x0 = _flat(cast(x, dt))
 		wqkv_c, wo_c, w1_c, w2_c = (weight_as(t, dt) for t in (wqkv, wo, w1, w2))
 		n1, _, mean1, rstd1 = norm_fwd(x0, f32(n1w), f32(n1b), kind, eps, unit_offset)
-		if ls1 is None:
-			x1, qkv, o, lse = _mha_forward(n1, wqkv_c, wo_c, f32(bo), B, S, n_head, residual=x0)
+		if ls1 is None and d_a[0] == 0.0:
+			x1, qkv, o, lse = _mha_forward(n1, wqkv_c, wo_c, f32(bo), B, S, n_head, residual=x0, drop=d_attn)
+			br1 = None
+		elif ls1 is None:
+			x1, qkv, o, lse = _mha_forward(n1, wqkv_c, wo_c, f32(bo), B, S, n_head, drop=d_attn)
+			dropout_add(x1, x0, d_a[0], d_a[1], out=x1)  # x0 + dropout(branch), in the branch's buffer
 			br1 = None
 		else:
 			br1, qkv, o, lse = _mha_forward(n1, wqkv_c, wo_c, f32(bo), B, S, n_head)
 			x1 = scale_residual(br1, x0, f32(ls1))
 		n2, _, mean2, rstd2 = norm_fwd(x1, f32(n2w), f32(n2b), kind, eps, unit_offset)
-		if ls2 is None:
-			x2, u, a = _ffn_forward(n2, w1_c, f32(b1), w2_c, f32(b2), act, gated, residual=x1)
+		if ls2 is None and d_f2[0] == 0.0 and d_b[0] == 0.0:
+			x2, u, a = _ffn_forward(n2, w1_c, f32(b1), w2_c, f32(b2), act, gated, residual=x1, drop1=d_f1)
+			br2 = None
+		elif ls2 is None:
+			x2, u, a = _ffn_forward(n2, w1_c, f32(b1), w2_c, f32(b2), act, gated, drop1=d_f1)
+			m1, m2 = (d_f2, d_b) if d_f2[0] > 0.0 else (d_b, off)
+			dropout_add(x2, x1, m1[0], m1[1], m2[0], m2[1], out=x2)
 			br2 = None
 		else:
 			br2, u, a = _ffn_forward(n2, w1_c, f32(b1), w2_c, f32(b2), act, gated)
@@ -601,26 +630,34 @@ class ViTBlockFn(torch.autograd.Function):
 	def backward(ctx, dy):
 		(x0, n1, mean1, rstd1, qkv, o, lse, br1, x1, n2, mean2, rstd2, u, a, br2, n1w, wqkv, wo, ls1, n2w, w1, w2, ls2) = ctx.saved_tensors
 		(B, S, d), xdtype, n1b, bo, n2b, b1, b2, cfg, dt = ctx.meta
-		kind, eps, unit_offset, n_head, act, gated = cfg
+		kind, eps, unit_offset, n_head, act, gated = cfg[:6]
+		dr = cfg[6] if len(cfg) > 6 and cfg[6] is not None else {}
+		off = (0.0, 0)
+		d_attn, d_a, d_f1, d_f2, d_b = (dr.get(k, off) for k in ("attn", "a", "f1", "f2", "b"))
 		wqkv_c, wo_c, w1_c, w2_c = (weight_as(t, dt) for t in (wqkv, wo, w1, w2))
 		dx2 = _flat(cast(dy, dt))
 		# feed-forward branch
 		if ls2 is not None:
 			dbr2, dls2 = layerscale_bwd(dx2, br2, f32(ls2))
+		elif d_f2[0] > 0.0 or d_b[0] > 0.0:
+			m1, m2 = (d_f2, d_b) if d_f2[0] > 0.0 else (d_b, off)
+			dbr2, dls2 = dropout_add(dx2, None, m1[0], m1[1], m2[0], m2[1]), None
 		else:
 			dbr2, dls2 = dx2, None
 		# parameters with a registered gradient sink get their gradients accumulated in place by the kernels
 		sk = {n: _sink(t) for n, t in (("n1w", n1w), ("n1b", n1b), ("wqkv", wqkv), ("wo", wo), ("bo", bo), ("n2w", n2w), ("n2b", n2b), ("w1", w1), ("b1", b1),
 			("w2", w2), ("b2", b2))}
 		buf = {n: (v[0] if v is not None else None) for n, v in sk.items()}
-		dn2, dw1, db1, dw2, db2 = _ffn_backward(dbr2, n2, u, a, w1_c, w2_c, act, gated, outs=(buf["w1"], buf["b1"], buf["w2"], buf["b2"]))
+		dn2, dw1, db1, dw2, db2 = _ffn_backward(dbr2, n2, u, a, w1_c, w2_c, act, gated, outs=(buf["w1"], buf["b1"], buf["w2"], buf["b2"]), drop1=d_f1)
 		dx1, dn2w, dn2b = norm_bwd(dn2, x1, f32(n2w), mean2, rstd2, kind, unit_offset, dres=dx2, dw_out=buf["n2w"], db_out=buf["n2b"])
 		# attention branch
 		if ls1 is not None:
 			dbr1, dls1 = layerscale_bwd(dx1, br1, f32(ls1))
+		elif d_a[0] > 0.0:
+			dbr1, dls1 = dropout_add(dx1, None, d_a[0], d_a[1]), None
 		else:
 			dbr1, dls1 = dx1, None
-		dn1, dwqkv, dwo, dbo = _mha_backward(dbr1, n1, qkv, o, lse, wqkv_c, wo_c, B, S, n_head, outs=(buf["wqkv"], buf["wo"], buf["bo"]))
+		dn1, dwqkv, dwo, dbo = _mha_backward(dbr1, n1, qkv, o, lse, wqkv_c, wo_c, B, S, n_head, outs=(buf["wqkv"], buf["wo"], buf["bo"]), drop=d_attn)
 		dx0, dn1w, dn1b = norm_bwd(dn1, x0, f32(n1w), mean1, rstd1, kind, unit_offset, dres=dx1, dw_out=buf["n1w"], db_out=buf["n1b"])
 		dx0 = dx0.reshape(B, S, d)
 		if dx0.dtype != xdtype:
