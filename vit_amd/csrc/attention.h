@@ -16,6 +16,7 @@ struct AttnArgs {
 	// ones are scaled by drop_scale = 65536 / (65536 - drop_thr16)
 	uint32_t drop_thr16, seed_lo, seed_hi;
 	float drop_scale;
+	int heads_per_wg;  // set by the launcher: consecutive (batch, head) pairs one workgroup of the forward kernel walks
 };
 
 // The dropout mask is a pure function of (seed, batch * n_head + head, query, key), so the forward and both backward

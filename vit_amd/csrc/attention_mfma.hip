@@ -78,29 +78,84 @@ __device__ __forceinline__ float group_sum(float v) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// staging by LDS-DMA
+// ---------------------------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void* lds_void_p;
+typedef const __attribute__((address_space(1))) void* gbl_void_p;
+
+// Rows [0, rows_pad) x 64 columns of a [*, ld] bf16 matrix into an LDS image by global_load_lds_dwordx4: a
+// wave-instruction fills 8 image rows (1 KiB, written linearly at a wave-uniform address); the image's chunk swizzle is
+// applied to each lane's SOURCE address.  Rows past rows_valid re-read the last valid row (finite values that only ever
+// meet zero probabilities).  Pieces are dealt round-robin to the waves; nothing is waited for here.
+__device__ __forceinline__ void stage_image_dma(char* img, const bf16_t* src, int64_t ld, int rows_valid, int rows_pad, int wave, int nwaves, int lane) {
+	const int r8 = lane >> 3, slot = lane & 7;
+	for (int piece = wave; piece < (rows_pad >> 3); piece += nwaves) {
+		const int row = 8 * piece + r8;
+		const int rs = row < rows_valid ? row : rows_valid - 1;
+		const bf16_t* p = src + (int64_t)rs * ld + 8 * (slot ^ (row & 7));
+		__builtin_amdgcn_global_load_lds((gbl_void_p)p, (lds_void_p)(img + piece * 1024), 16, 0, 0);
+	}
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------------------------------
+// A workgroup walks `a.heads_per_wg` consecutive (batch, head) pairs with two K/V image buffers: while it works on one
+// pair the LDS-DMA of the next pair's keys and values is in flight, and each wave already holds the next pair's query
+// rows in registers.  (One workgroup per pair spends most of its life waiting for its own K/V and Q to arrive: with
+// everything else left out, the staging and launch skeleton alone took 100 of that kernel's 130 us on ViT-B/16.)
 template <int KT2, bool DROP>  // keys padded to 32 * KT2; DROP: attention-probability dropout
 __global__ __launch_bounds__(1024) void attn_fwd_mfma_kernel(AttnArgs a) {
 	extern __shared__ __attribute__((aligned(16))) char smem[];
-	char* Ks = smem;
-	char* Vs = smem + KT2 * 32 * 128;
-	const int b = blockIdx.x / a.n_head, h = blockIdx.x % a.n_head;
-	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+	constexpr int IMG = KT2 * 32 * 128;  // one image
+	const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nwaves = blockDim.x >> 6;
 	const int g = lane >> 4;
-	const bf16_t* kb = reinterpret_cast<const bf16_t*>(a.k) + (int64_t)b * a.Skv * a.ldk + h * DH;
-	const bf16_t* vb = reinterpret_cast<const bf16_t*>(a.v) + (int64_t)b * a.Skv * a.ldv + h * DH;
-	stage_image(Ks, kb, a.ldk, a.Skv, KT2 * 32);
-	stage_image(Vs, vb, a.ldv, a.Skv, KT2 * 32);
-	__syncthreads();
+	const int n_bh = a.B * a.n_head;
+	const int bh0 = blockIdx.x * a.heads_per_wg;
+	const int bh1 = min(n_bh, bh0 + a.heads_per_wg);
 	const float c = a.scale * LOG2E;
-	const int n_qtiles = (a.Sq + 15) >> 4;
-	for (int qt = wave; qt < n_qtiles; qt += nwaves) {
-		const int q = qt * 16 + (lane & 15);
-		const int qc = q < a.Sq ? q : a.Sq - 1;
-		const bf16_t* qp = reinterpret_cast<const bf16_t*>(a.q) + ((int64_t)b * a.Sq + qc) * a.ldq + h * DH + 8 * g;
-		const bf16x8 qf0 = *reinterpret_cast<const bf16x8*>(qp);
-		const bf16x8 qf1 = *reinterpret_cast<const bf16x8*>(qp + 32);
+	const int n_qtiles = (a.Sq + 15) >> 4;  // <= number of waves: one query tile per wave and pair
+	const bool active = wave < n_qtiles;
+	const int q = wave * 16 + (lane & 15);
+	const int qc = q < a.Sq ? q : a.Sq - 1;
+
+	auto stage = [&](int bh, int buf) {
+		const int b = bh / a.n_head, h = bh - b * a.n_head;
+		const bf16_t* kb = reinterpret_cast<const bf16_t*>(a.k) + (int64_t)b * a.Skv * a.ldk + h * DH;
+		const bf16_t* vb = reinterpret_cast<const bf16_t*>(a.v) + (int64_t)b * a.Skv * a.ldv + h * DH;
+		stage_image_dma(smem + buf * 2 * IMG, kb, a.ldk, a.Skv, KT2 * 32, wave, nwaves, lane);
+		stage_image_dma(smem + buf * 2 * IMG + IMG, vb, a.ldv, a.Skv, KT2 * 32, wave, nwaves, lane);
+	};
+	auto q_ptr = [&](int bh) {
+		const int b = bh / a.n_head, h = bh - b * a.n_head;
+		return reinterpret_cast<const bf16_t*>(a.q) + ((int64_t)b * a.Sq + qc) * a.ldq + h * DH + 8 * g;
+	};
+
+	bf16x8 qn0 = {}, qn1 = {};
+	if (active) {
+		const bf16_t* qp = q_ptr(bh0);
+		qn0 = *reinterpret_cast<const bf16x8*>(qp);
+		qn1 = *reinterpret_cast<const bf16x8*>(qp + 32);
+	}
+	stage(bh0, 0);
+	for (int bh = bh0; bh < bh1; ++bh) {
+		const int buf = (bh - bh0) & 1;
+		// this pair's images have landed (the barrier's fence drains the DMA, and with it the query rows requested
+		// before it) and every wave is done with the other buffer
+		__syncthreads();
+		const bf16x8 qf0 = qn0, qf1 = qn1;
+		if (bh + 1 < bh1) {
+			stage(bh + 1, buf ^ 1);
+			if (active) {
+				const bf16_t* qp = q_ptr(bh + 1);
+				qn0 = *reinterpret_cast<const bf16x8*>(qp);
+				qn1 = *reinterpret_cast<const bf16x8*>(qp + 32);
+			}
+		}
+		if (!active) continue;
+		const char* Ks = smem + buf * 2 * IMG;
+		const char* Vs = Ks + IMG;
+		const int b = bh / a.n_head, h = bh - b * a.n_head;
 		f32x4 st[2 * KT2];
 		float m = -INFINITY;
 #pragma unroll
@@ -108,7 +163,7 @@ __global__ __launch_bounds__(1024) void attn_fwd_mfma_kernel(AttnArgs a) {
 			f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 			acc = mfma16(row_frag(Ks, 16 * t, 0, lane), qf0, acc);
 			acc = mfma16(row_frag(Ks, 16 * t, 1, lane), qf1, acc);
-			if (16 * t + 16 > a.Skv) {  // wave-uniform: only the tile(s) that reach past the last key pay for the mask
+			if (t >= 2 * KT2 - 2) {  // 32 (KT2 - 1) < Skv <= 32 KT2: only the last two tiles can reach past the last key
 #pragma unroll
 				for (int r = 0; r < 4; ++r)
 					if (16 * t + 4 * g + r >= a.Skv) acc[r] = -INFINITY;
@@ -132,7 +187,7 @@ __global__ __launch_bounds__(1024) void attn_fwd_mfma_kernel(AttnArgs a) {
 		l = group_sum(l);
 		if constexpr (DROP) {
 			// the normaliser l is that of the full softmax; dropped probabilities leave the P V product only
-			const uint32_t rk = attn_row_key(attn_head_key(a, blockIdx.x), q);
+			const uint32_t rk = attn_row_key(attn_head_key(a, bh), q);
 #pragma unroll
 			for (int t = 0; t < 2 * KT2; ++t) {
 				const int k0 = 16 * t + 4 * g;
@@ -163,7 +218,7 @@ __global__ __launch_bounds__(1024) void attn_fwd_mfma_kernel(AttnArgs a) {
 				for (int r = 0; r < 4; ++r) ov[r] = (bf16_t)(o[dt][r] * inv);
 				*reinterpret_cast<bf16x4*>(op + 16 * dt) = ov;
 			}
-			if (g == 0) a.lse[((int64_t)b * a.n_head + h) * a.Sq + q] = m * a.scale + __logf(l);
+			if (g == 0) a.lse[(int64_t)bh * a.Sq + q] = m * a.scale + __logf(l);
 		}
 	}
 }
@@ -338,8 +393,8 @@ __global__ __launch_bounds__(1024) void attn_bwd_dkv_mfma_kernel(AttnArgs a) {
 				}
 #pragma unroll
 				for (int r = 0; r < 4; ++r) {
-					float pr = __builtin_amdgcn_exp2f(s[r] * c - l4[r]);
-					if (!key_ok) pr = 0.f;
+					// (lanes of keys past the last one work on a re-read row; their sums are never stored)
+					const float pr = __builtin_amdgcn_exp2f(s[r] * c - l4[r]);
 					p[hf][r] = DROP ? pr * keep[r] : pr;  // dV = (P o M)^T dO
 					ds[hf][r] = pr * ((DROP ? dp[r] * keep[r] : dp[r]) - d4[r]) * a.scale;
 				}
@@ -370,17 +425,30 @@ __global__ __launch_bounds__(1024) void attn_bwd_dkv_mfma_kernel(AttnArgs a) {
 	}
 }
 
+// consecutive (batch, head) pairs per workgroup of the forward kernel: as many as still leave every CU a workgroup
+int heads_per_workgroup(int n_bh) {
+	static int cus = 0;
+	if (cus == 0) {
+		int dev = 0;
+		if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+	}
+	return std::max(1, std::min(16, n_bh / cus));
+}
+
 template <int T2, bool DROP>
-int launch_fwd(const AttnArgs& a, hipStream_t st) {
-	const int nw = std::min(16, (a.Sq + 15) / 16);
-	const size_t lds = (size_t)2 * T2 * 32 * 128;
+int launch_fwd(const AttnArgs& a0, hipStream_t st) {
+	AttnArgs a = a0;
+	const int nw = (a.Sq + 15) / 16;  // one wave per 16-query tile (<= 16: the kernels cover up to 256 queries)
+	const int n_bh = a.B * a.n_head;
+	a.heads_per_wg = heads_per_workgroup(n_bh);
+	const size_t lds = (size_t)4 * T2 * 32 * 128;  // two buffers of a K and a V image
 	static bool attr = false;
 	if (!attr) {
 		hipError_t e = hipFuncSetAttribute((const void*)attn_fwd_mfma_kernel<T2, DROP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 		if (e != hipSuccess) return VITK_ERR_HIP - (int)e;
 		attr = true;
 	}
-	hipLaunchKernelGGL((attn_fwd_mfma_kernel<T2, DROP>), dim3((unsigned)(a.B * a.n_head)), dim3(64 * nw), lds, st, a);
+	hipLaunchKernelGGL((attn_fwd_mfma_kernel<T2, DROP>), dim3((unsigned)vitk_cdiv(n_bh, a.heads_per_wg)), dim3(64 * nw), lds, st, a);
 	VITK_CHECK_LAUNCH();
 	return VITK_OK;
 }
