@@ -196,6 +196,14 @@ def main():
 				"gflop_per_launch": round(fl / n / 1e9, 2),
 				"traffic_unit": "bytes per vitk_gemm call (HBM-side, PMC)", "traffic_source": traffic_src,
 				"all_gemm_kernels": {k: {"tflops": round(v[0] / v[1] / 1e12, 1), "ms_per_step": round(1e3 * v[1] / args.steps, 3), "launches_per_step": v[2] // args.steps} for k, v in agg.items()}}
+			# matrix-pipe busy fraction of the same workload from an SQ counter pass (SQ_VALU_MFMA_BUSY_CYCLES over
+			# 4 x SQ_BUSY_CU_CYCLES, i.e. against the clock the chip actually ran at): recorded, not measured in this run
+			spath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1_pmc_sq_counters.json")
+			if args.config == "vit_b16" and os.path.exists(spath):
+				for key, rec in json.load(open(spath)).items():
+					if key.startswith("whole training step"):
+						out["roofline"]["mfma_pipe_busy_frac_whole_step_pmc"] = round(rec["derived_mfma_pipe_busy_frac"], 4)
+						out["roofline"]["mfma_pipe_busy_source"] = "profiles/r1_pmc_sq_counters.json"
 		if not args.no_cpu_baseline and world == 1:
 			out["cpu_baseline"] = cpu_baseline(c)
 		print(json.dumps(out), flush=True)
