@@ -146,7 +146,8 @@ int vitk_rmsnorm_bwd(const void* dy, const void* x, const float* weight, const f
  * 'b s (h d)' layout the projections produce, so q/k/v may be column slices of one fused
  * [B, S, 3*d_model] buffer.  k, v are [B, Skv, *].  out is [B, Sq, n_head*dh] with row stride ldo.
  * lse [B, n_head, Sq] float32 = log-sum-exp of the scaled scores, saved for the backward.
- * scale <= 0 selects 1/sqrt(dh).  Backward needs out and lse of the forward.
+ * scale <= 0 selects 1/sqrt(dh).  Backward needs out and lse of the forward, and `scratch`: 2 * B * n_head * Sq
+ * floats of caller-provided device memory (its dQ pass leaves the per-row softmax statistics there for its dK/dV pass).
  */
 int vitk_attention_fwd(const void* q, const void* k, const void* v, void* out, float* lse,
 	int64_t B, int64_t n_head, int64_t Sq, int64_t Skv, int64_t dh,
@@ -155,7 +156,7 @@ int vitk_attention_bwd(const void* dout, const void* q, const void* k, const voi
 	void* dq, void* dk, void* dv,
 	int64_t B, int64_t n_head, int64_t Sq, int64_t Skv, int64_t dh,
 	int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t lddq, int64_t lddk, int64_t lddv,
-	float scale, int dtype, void* stream);
+	float scale, float* scratch, int dtype, void* stream);
 /* The same with dropout on the attention probabilities: the `dropout_p` argument of
  * F.scaled_dot_product_attention in training mode (layers/attention.py:41,86):
  * out = (softmax(q k^T * scale) o M / (1 - p)) v with a keep mask M.  M is a pure function of
@@ -169,7 +170,7 @@ int vitk_attention_bwd_dropout(const void* dout, const void* q, const void* k, c
 	void* dq, void* dk, void* dv,
 	int64_t B, int64_t n_head, int64_t Sq, int64_t Skv, int64_t dh,
 	int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t lddq, int64_t lddk, int64_t lddv,
-	float scale, float dropout_p, uint64_t seed, int dtype, void* stream);
+	float scale, float dropout_p, uint64_t seed, float* scratch, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Bandwidth-bound elementwise / reduction kernels.

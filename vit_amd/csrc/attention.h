@@ -16,6 +16,7 @@ struct AttnArgs {
 	// ones are scaled by drop_scale = 65536 / (65536 - drop_thr16)
 	uint32_t drop_thr16, seed_lo, seed_hi;
 	float drop_scale;
+	float* bwd_scratch;  // backward: [2][B * n_head * Sq] floats (lse in log2 units, delta = rowsum(dO o O)): dQ kernel -> dK/dV kernel
 	int heads_per_wg;  // set by the launcher: consecutive (batch, head) pairs one workgroup of the forward kernel walks
 };
 

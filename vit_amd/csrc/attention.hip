@@ -49,12 +49,13 @@ extern "C" int vitk_attention_fwd(const void* q, const void* k, const void* v, v
 
 extern "C" int vitk_attention_bwd_dropout(const void* dout, const void* q, const void* k, const void* v, const void* out, const float* lse, void* dq,
 	void* dk, void* dv, int64_t B, int64_t n_head, int64_t Sq, int64_t Skv, int64_t dh, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
-	int64_t lddq, int64_t lddk, int64_t lddv, float scale, float dropout_p, uint64_t seed, int dtype, void* stream) {
-	VITK_REQUIRE(dout && q && k && v && out && lse && dq && dk && dv, VITK_ERR_NULL);
+	int64_t lddq, int64_t lddk, int64_t lddv, float scale, float dropout_p, uint64_t seed, float* scratch, int dtype, void* stream) {
+	VITK_REQUIRE(dout && q && k && v && out && lse && dq && dk && dv && scratch, VITK_ERR_NULL);
 	VITK_REQUIRE(B < (1ll << 31) && n_head < (1ll << 31) && Sq < (1ll << 31) && Skv < (1ll << 31) && dh < (1ll << 31), VITK_ERR_SHAPE);
 	AttnArgs a{};
 	a.q = q; a.k = k; a.v = v; a.out = out; a.dout = dout; a.lse = const_cast<float*>(lse);
 	a.dq = dq; a.dk = dk; a.dv = dv;
+	a.bwd_scratch = scratch;
 	a.B = (int)B; a.n_head = (int)n_head; a.Sq = (int)Sq; a.Skv = (int)Skv; a.dh = (int)dh;
 	a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.lddq = lddq; a.lddk = lddk; a.lddv = lddv;
 	a.scale = scale > 0.f ? scale : 1.0f / sqrtf((float)dh);
@@ -70,7 +71,7 @@ extern "C" int vitk_attention_bwd_dropout(const void* dout, const void* q, const
 
 extern "C" int vitk_attention_bwd(const void* dout, const void* q, const void* k, const void* v, const void* out, const float* lse, void* dq,
 	void* dk, void* dv, int64_t B, int64_t n_head, int64_t Sq, int64_t Skv, int64_t dh, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
-	int64_t lddq, int64_t lddk, int64_t lddv, float scale, int dtype, void* stream) {
-	return vitk_attention_bwd_dropout(dout, q, k, v, out, lse, dq, dk, dv, B, n_head, Sq, Skv, dh, ldq, ldk, ldv, ldo, lddq, lddk, lddv, scale, 0.f, 0, dtype,
-		stream);
+	int64_t lddq, int64_t lddk, int64_t lddv, float scale, float* scratch, int dtype, void* stream) {
+	return vitk_attention_bwd_dropout(dout, q, k, v, out, lse, dq, dk, dv, B, n_head, Sq, Skv, dh, ldq, ldk, ldv, ldo, lddq, lddk, lddv, scale, 0.f, 0, scratch,
+		dtype, stream);
 }

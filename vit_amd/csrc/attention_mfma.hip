@@ -256,6 +256,10 @@ __global__ __launch_bounds__(1024) void attn_bwd_dq_mfma_kernel(AttnArgs a) {
 		for (int j = 0; j < 8; ++j) delta += (float)gf0[j] * (float)of0[j] + (float)gf1[j] * (float)of1[j];
 		delta = group_sum(delta);
 		const float lse2 = a.lse[((int64_t)b * a.n_head + h) * a.Sq + qc] * LOG2E;
+		if (g == 0 && q < a.Sq) {  // row statistics for the dK/dV kernel, which runs after this one
+			a.bwd_scratch[(int64_t)blockIdx.x * a.Sq + q] = lse2;
+			a.bwd_scratch[((int64_t)gridDim.x + blockIdx.x) * a.Sq + q] = delta;
+		}
 		const uint32_t rk = DROP ? attn_row_key(attn_head_key(a, blockIdx.x), q) : 0u;
 		f32x4 dq[4];
 #pragma unroll
@@ -311,119 +315,230 @@ __global__ __launch_bounds__(1024) void attn_bwd_dq_mfma_kernel(AttnArgs a) {
 // ---------------------------------------------------------------------------------------------------------------
 // backward: dK, dV (key on the lane)
 // ---------------------------------------------------------------------------------------------------------------
+// Transposing LDS reads as inline asm that is issued but not waited for (lgkm_wait retires them).  Two reasons: hipcc
+// puts s_waitcnt vmcnt(0) in front of the builtin whenever an LDS-DMA request is in flight (it would wait for the NEXT
+// pair's images), and it schedules every builtin read right in front of its MFMA, one LDS round trip per MFMA.
+// `addr`: LDS byte address of the lane's fragment in step 0 of the first image; OFF: constant byte offset (image).
+template <int OFF>
+__device__ __forceinline__ void tr_issue(uint32_t addr, s16x4& lo, s16x4& hi) {
+	asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(addr), "n"(OFF));
+	asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(addr), "n"(OFF + 2048));
+}
+// waits until every LDS read issued so far has returned; names the registers so that no use can move above the wait
+__device__ __forceinline__ void lgkm_wait(s16x4 (&f)[4][2]) {
+	asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0][0]), "+v"(f[0][1]), "+v"(f[1][0]), "+v"(f[1][1]), "+v"(f[2][0]), "+v"(f[2][1]), "+v"(f[3][0]), "+v"(f[3][1]));
+}
+__device__ __forceinline__ bf16x8 join8(s16x4 lo, s16x4 hi) {
+	union {
+		s16x4 h[2];
+		bf16x8 v;
+	} u;
+	u.h[0] = lo;
+	u.h[1] = hi;
+	return u.v;
+}
+__device__ __forceinline__ uint32_t lds_addr(const char* p) {
+	typedef __attribute__((address_space(3))) void* lds_p;
+	return (uint32_t)(uintptr_t)(lds_p)(void*)p;
+}
+
+// Eight waves per workgroup (two per SIMD, so a lane may use 256 registers), each wave owns up to two 16-key tiles and
+// sums over all queries; a workgroup walks consecutive (batch, head) pairs.  Two buffers of {Q image, dO image, lse[q]
+// (log2 units), delta[q] = sum_d dO O} are filled by LDS-DMA, the last two from the scratch the dQ kernel wrote; the
+// next pair's K / V rows are already in registers.  Per 32 queries: (A) all eight row fragments are requested, (B) the S
+// and dP MFMAs run, (C) the eight transposed fragments for the dV / dK products are requested, (D) the softmax
+// arithmetic covers their latency, (E) the dV / dK MFMAs: two exposed LDS round trips per step instead of the fourteen
+// of a one-read-per-MFMA schedule.  (The same form with one tile per wave and 13 waves has 128 registers per lane,
+// spills, and is slower than the plain kernel it replaced: 176 -> 137 us per ViT-B/16 layer needs the registers.)
 template <int QT2, bool DROP>  // queries padded to 32 * QT2
-__global__ __launch_bounds__(1024) void attn_bwd_dkv_mfma_kernel(AttnArgs a) {
+__global__ __launch_bounds__(512) void attn_bwd_dkv_mfma_kernel(AttnArgs a) {
 	extern __shared__ __attribute__((aligned(16))) char smem[];
-	constexpr int QP = QT2 * 32;
-	char* Qs = smem;
-	char* Gs = smem + QP * 128;
-	float* lse_s = reinterpret_cast<float*>(smem + 2 * QP * 128);
-	float* del_s = lse_s + QP;
-	uint32_t* rk_s = reinterpret_cast<uint32_t*>(del_s + QP);  // dropout: mask key of every query row
-	const int b = blockIdx.x / a.n_head, h = blockIdx.x % a.n_head;
-	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+	constexpr int QP = QT2 * 32, IMG = QP * 128;
+	constexpr int QF = (QP + 63) & ~63;
+	constexpr int BUF = 2 * IMG + 2 * QF * 4;
+	uint32_t* rk_s = reinterpret_cast<uint32_t*>(smem + 2 * BUF);
+	const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	constexpr int NW = 8;
 	const int g = lane >> 4;
-	if constexpr (DROP) {
-		const uint32_t hk = attn_head_key(a, blockIdx.x);
-		for (int r = threadIdx.x; r < QP; r += blockDim.x) rk_s[r] = attn_row_key(hk, r);
-	}
-	const bf16_t* qb = reinterpret_cast<const bf16_t*>(a.q) + (int64_t)b * a.Sq * a.ldq + h * DH;
-	const bf16_t* gb = reinterpret_cast<const bf16_t*>(a.dout) + (int64_t)b * a.Sq * a.ldo + h * DH;
-	const bf16_t* ob = reinterpret_cast<const bf16_t*>(a.out) + (int64_t)b * a.Sq * a.ldo + h * DH;
-	stage_image(Qs, qb, a.ldq, a.Sq, QP);
-	// dO image + delta[q] = sum_d dO[q][d] O[q][d] (8 lanes per row, one 16-byte chunk each) + lse (in log2 units)
-	for (int idx = threadIdx.x; idx < QP * 8; idx += blockDim.x) {
-		const int r = idx >> 3, cc = idx & 7;
-		uint4 gv = make_uint4(0, 0, 0, 0), ov = make_uint4(0, 0, 0, 0);
-		if (r < a.Sq) {
-			gv = *reinterpret_cast<const uint4*>(gb + (int64_t)r * a.ldo + 8 * cc);
-			ov = *reinterpret_cast<const uint4*>(ob + (int64_t)r * a.ldo + 8 * cc);
-		}
-		*reinterpret_cast<uint4*>(Gs + img_off(r, cc)) = gv;
-		const bf16x8 g8 = *reinterpret_cast<const bf16x8*>(&gv), o8 = *reinterpret_cast<const bf16x8*>(&ov);
-		float d = 0.f;
-#pragma unroll
-		for (int j = 0; j < 8; ++j) d += (float)g8[j] * (float)o8[j];
-		d += __shfl_xor(d, 1, 64);
-		d += __shfl_xor(d, 2, 64);
-		d += __shfl_xor(d, 4, 64);
-		if (cc == 0) {
-			del_s[r] = d;
-			// padded queries: lse = +inf makes their probabilities exactly zero
-			lse_s[r] = r < a.Sq ? a.lse[((int64_t)b * a.n_head + h) * a.Sq + r] * LOG2E : INFINITY;
-		}
-	}
-	__syncthreads();
+	const int n_bh = a.B * a.n_head;
+	const int bh0 = blockIdx.x * a.heads_per_wg;
+	const int bh1 = min(n_bh, bh0 + a.heads_per_wg);
 	const float c = a.scale * LOG2E;
-	const int n_ktiles = (a.Skv + 15) >> 4;
-	for (int kt = wave; kt < n_ktiles; kt += nwaves) {
-		const int key = kt * 16 + (lane & 15);
-		const bool key_ok = key < a.Skv;
-		const int64_t krow = (int64_t)b * a.Skv + (key_ok ? key : a.Skv - 1);
-		const bf16_t* kp = reinterpret_cast<const bf16_t*>(a.k) + krow * a.ldk + h * DH + 8 * g;
-		const bf16_t* vp = reinterpret_cast<const bf16_t*>(a.v) + krow * a.ldv + h * DH + 8 * g;
-		const bf16x8 kf0 = *reinterpret_cast<const bf16x8*>(kp), kf1 = *reinterpret_cast<const bf16x8*>(kp + 32);
-		const bf16x8 vf0 = *reinterpret_cast<const bf16x8*>(vp), vf1 = *reinterpret_cast<const bf16x8*>(vp + 32);
-		f32x4 dk[4], dv[4];
-#pragma unroll
-		for (int dt = 0; dt < 4; ++dt) {
-			dk[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-			dv[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+	const int n_ktiles = (a.Skv + 15) >> 4;  // <= 16: two tile slots per wave
+
+	auto stage = [&](int bh, int buf) {
+		const int b = bh / a.n_head, h = bh - b * a.n_head;
+		char* base = smem + buf * BUF;
+		const bf16_t* qb = reinterpret_cast<const bf16_t*>(a.q) + (int64_t)b * a.Sq * a.ldq + h * DH;
+		const bf16_t* gb = reinterpret_cast<const bf16_t*>(a.dout) + (int64_t)b * a.Sq * a.ldo + h * DH;
+		stage_image_dma(base, qb, a.ldq, a.Sq, QP, wave, NW, lane);
+		stage_image_dma(base + IMG, gb, a.ldo, a.Sq, QP, wave, NW, lane);
+		for (int piece = wave; piece < 2 * (QF / 64); piece += NW) {
+			const int which = piece / (QF / 64), pp = piece - which * (QF / 64);
+			const int qi = 64 * pp + lane;
+			const float* src = a.bwd_scratch + ((int64_t)which * n_bh + bh) * a.Sq + qi;
+			if (qi < a.Sq) __builtin_amdgcn_global_load_lds((gbl_void_p)src, (lds_void_p)(base + 2 * IMG + (which * QF + 64 * pp) * 4), 4, 0, 0);
 		}
+	};
+	bf16x8 nk[2][2], nv[2][2];
+#pragma unroll
+	for (int j = 0; j < 2; ++j)
+#pragma unroll
+		for (int s2 = 0; s2 < 2; ++s2) nk[j][s2] = nv[j][s2] = bf16x8{};
+	auto fetch_rows = [&](int bh) {
+		const int b = bh / a.n_head, h = bh - b * a.n_head;
+#pragma unroll
+		for (int j = 0; j < 2; ++j) {
+			if (wave + NW * j < n_ktiles) {
+				const int key = (wave + NW * j) * 16 + (lane & 15);
+				const int64_t krow = (int64_t)b * a.Skv + min(key, a.Skv - 1);
+				const bf16_t* kp = reinterpret_cast<const bf16_t*>(a.k) + krow * a.ldk + h * DH + 8 * g;
+				const bf16_t* vp = reinterpret_cast<const bf16_t*>(a.v) + krow * a.ldv + h * DH + 8 * g;
+				nk[j][0] = *reinterpret_cast<const bf16x8*>(kp), nk[j][1] = *reinterpret_cast<const bf16x8*>(kp + 32);
+				nv[j][0] = *reinterpret_cast<const bf16x8*>(vp), nv[j][1] = *reinterpret_cast<const bf16x8*>(vp + 32);
+			}
+		}
+	};
+	auto row_keys = [&](int bh, int buf) {
+		if constexpr (DROP) {
+			const uint32_t hk = attn_head_key(a, bh);
+			for (int r = threadIdx.x; r < QP; r += blockDim.x) rk_s[buf * QP + r] = attn_row_key(hk, r);
+		}
+	};
+	// queries past the last one: lse = +inf makes their probabilities exactly zero (the DMA never writes these slots)
+	for (int i = threadIdx.x; i < 2 * 2 * QF; i += blockDim.x) {
+		const int bi = i / (2 * QF), r = i - bi * 2 * QF;
+		float* arr = reinterpret_cast<float*>(smem + bi * BUF + 2 * IMG);
+		if ((r < QF ? r : r - QF) >= a.Sq) arr[r] = r < QF ? INFINITY : 0.f;
+	}
+	// byte offsets of a lane's fragment reads (the tile / step part is added as an immediate)
+	int rf[2];
+	uint32_t trb[4];
+#pragma unroll
+	for (int s2 = 0; s2 < 2; ++s2) rf[s2] = img_off(lane & 15, 4 * s2 + g);
+	{
+		const int i = lane & 15, q4 = i >> 2, p = i & 3;
+#pragma unroll
+		for (int dt = 0; dt < 4; ++dt) trb[dt] = img_off(4 * g + q4, 2 * dt + (p >> 1)) + ((p & 1) << 3);
+	}
+	fetch_rows(bh0);
+	stage(bh0, 0);
+	row_keys(bh0, 0);
+	for (int bh = bh0; bh < bh1; ++bh) {
+		const int buf = (bh - bh0) & 1;
+		__syncthreads();
+		bf16x8 ck[2][2], cv[2][2];
+#pragma unroll
+		for (int j = 0; j < 2; ++j)
+#pragma unroll
+			for (int s2 = 0; s2 < 2; ++s2) {
+				ck[j][s2] = nk[j][s2];
+				cv[j][s2] = nv[j][s2];
+			}
+		if (bh + 1 < bh1) {
+			stage(bh + 1, buf ^ 1);
+			row_keys(bh + 1, buf ^ 1);
+			fetch_rows(bh + 1);
+		}
+		const char* Qs = smem + buf * BUF;
+		const char* Gs = Qs + IMG;
+		const float* lse_s = reinterpret_cast<const float*>(Gs + IMG);
+		const float* del_s = lse_s + QF;
+		const int b = bh / a.n_head, h = bh - b * a.n_head;
+#pragma unroll
+		for (int j = 0; j < 2; ++j) {
+			if (wave + NW * j >= n_ktiles) continue;
+			const int key = (wave + NW * j) * 16 + (lane & 15);
+			f32x4 dk[4], dv[4];
+#pragma unroll
+			for (int dt = 0; dt < 4; ++dt) {
+				dk[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+				dv[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+			}
+			uint32_t tra[4];
+#pragma unroll
+			for (int dt = 0; dt < 4; ++dt) tra[dt] = lds_addr(Qs) + trb[dt];
+			const char* rq = Qs + rf[0];
+			const char* rq1 = Qs + rf[1];
 #pragma unroll 1
-		for (int u = 0; u < QT2; ++u) {
-			f32x4 p[2], ds[2];
+			for (int u = 0; u < QT2; ++u) {
+				f32x4 p[2], ds[2], sv[2], dpv[2];
+				bf16x8 fq[2][2], fg[2][2];
 #pragma unroll
-			for (int hf = 0; hf < 2; ++hf) {
-				const int t = 2 * u + hf;
-				f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-				s = mfma16(row_frag(Qs, 16 * t, 0, lane), kf0, s);
-				s = mfma16(row_frag(Qs, 16 * t, 1, lane), kf1, s);
-				dp = mfma16(row_frag(Gs, 16 * t, 0, lane), vf0, dp);
-				dp = mfma16(row_frag(Gs, 16 * t, 1, lane), vf1, dp);
-				const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_s + 16 * t + 4 * g);
-				const f32x4 d4 = *reinterpret_cast<const f32x4*>(del_s + 16 * t + 4 * g);
-				float keep[4] = {1.f, 1.f, 1.f, 1.f};
-				if constexpr (DROP) {
-					const uint4 rk4 = *reinterpret_cast<const uint4*>(rk_s + 16 * t + 4 * g);
-					keep[0] = attn_keep(attn_pair_bits(rk4.x, key >> 1), key, a.drop_thr16, a.drop_scale);
-					keep[1] = attn_keep(attn_pair_bits(rk4.y, key >> 1), key, a.drop_thr16, a.drop_scale);
-					keep[2] = attn_keep(attn_pair_bits(rk4.z, key >> 1), key, a.drop_thr16, a.drop_scale);
-					keep[3] = attn_keep(attn_pair_bits(rk4.w, key >> 1), key, a.drop_thr16, a.drop_scale);
+				for (int hf = 0; hf < 2; ++hf) {
+					fq[hf][0] = *reinterpret_cast<const bf16x8*>(rq + 4096 * u + 2048 * hf);
+					fq[hf][1] = *reinterpret_cast<const bf16x8*>(rq1 + 4096 * u + 2048 * hf);
+					fg[hf][0] = *reinterpret_cast<const bf16x8*>(rq + IMG + 4096 * u + 2048 * hf);
+					fg[hf][1] = *reinterpret_cast<const bf16x8*>(rq1 + IMG + 4096 * u + 2048 * hf);
+				}
+				__builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+				for (int hf = 0; hf < 2; ++hf) {
+					sv[hf] = mfma16(fq[hf][0], ck[j][0], (f32x4){0.f, 0.f, 0.f, 0.f});
+					dpv[hf] = mfma16(fg[hf][0], cv[j][0], (f32x4){0.f, 0.f, 0.f, 0.f});
 				}
 #pragma unroll
-				for (int r = 0; r < 4; ++r) {
-					// (lanes of keys past the last one work on a re-read row; their sums are never stored)
-					const float pr = __builtin_amdgcn_exp2f(s[r] * c - l4[r]);
-					p[hf][r] = DROP ? pr * keep[r] : pr;  // dV = (P o M)^T dO
-					ds[hf][r] = pr * ((DROP ? dp[r] * keep[r] : dp[r]) - d4[r]) * a.scale;
+				for (int hf = 0; hf < 2; ++hf) {
+					sv[hf] = mfma16(fq[hf][1], ck[j][1], sv[hf]);
+					dpv[hf] = mfma16(fg[hf][1], cv[j][1], dpv[hf]);
+				}
+				__builtin_amdgcn_sched_barrier(0);
+				s16x4 gt[4][2], qt[4][2];
+#pragma unroll
+				for (int dt = 0; dt < 4; ++dt) {
+					tr_issue<IMG>(tra[dt], gt[dt][0], gt[dt][1]);
+					tr_issue<0>(tra[dt], qt[dt][0], qt[dt][1]);
+					tra[dt] += 4096;
+				}
+#pragma unroll
+				for (int hf = 0; hf < 2; ++hf) {
+					const int t = 2 * u + hf;
+					const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_s + 16 * t + 4 * g);
+					const f32x4 d4 = *reinterpret_cast<const f32x4*>(del_s + 16 * t + 4 * g);
+					float keep[4] = {1.f, 1.f, 1.f, 1.f};
+					if constexpr (DROP) {
+						const uint4 rk4 = *reinterpret_cast<const uint4*>(rk_s + buf * QP + 16 * t + 4 * g);
+						keep[0] = attn_keep(attn_pair_bits(rk4.x, key >> 1), key, a.drop_thr16, a.drop_scale);
+						keep[1] = attn_keep(attn_pair_bits(rk4.y, key >> 1), key, a.drop_thr16, a.drop_scale);
+						keep[2] = attn_keep(attn_pair_bits(rk4.z, key >> 1), key, a.drop_thr16, a.drop_scale);
+						keep[3] = attn_keep(attn_pair_bits(rk4.w, key >> 1), key, a.drop_thr16, a.drop_scale);
+					}
+#pragma unroll
+					for (int r = 0; r < 4; ++r) {
+						const float pr = __builtin_amdgcn_exp2f(sv[hf][r] * c - l4[r]);
+						p[hf][r] = DROP ? pr * keep[r] : pr;
+						ds[hf][r] = pr * ((DROP ? dpv[hf][r] * keep[r] : dpv[hf][r]) - d4[r]) * a.scale;
+					}
+				}
+				const bf16x8 pf = pack8(p[0], p[1]);
+				const bf16x8 dsf = pack8(ds[0], ds[1]);
+				lgkm_wait(gt);
+				lgkm_wait(qt);
+#pragma unroll
+				for (int dt = 0; dt < 4; ++dt) {
+					dv[dt] = mfma16(join8(gt[dt][0], gt[dt][1]), pf, dv[dt]);
+					dk[dt] = mfma16(join8(qt[dt][0], qt[dt][1]), dsf, dk[dt]);
 				}
 			}
-			const bf16x8 pf = pack8(p[0], p[1]);
-			const bf16x8 dsf = pack8(ds[0], ds[1]);
+			if (key < a.Skv) {
+				bf16_t* dkp = reinterpret_cast<bf16_t*>(a.dk) + ((int64_t)b * a.Skv + key) * a.lddk + h * DH + 4 * g;
+				bf16_t* dvp = reinterpret_cast<bf16_t*>(a.dv) + ((int64_t)b * a.Skv + key) * a.lddv + h * DH + 4 * g;
 #pragma unroll
-			for (int dt = 0; dt < 4; ++dt) {
-				dv[dt] = mfma16(tr_frag(Gs, 32 * u, 32 * u + 16, 16 * dt, lane), pf, dv[dt]);
-				dk[dt] = mfma16(tr_frag(Qs, 32 * u, 32 * u + 16, 16 * dt, lane), dsf, dk[dt]);
-			}
-		}
-		if (key_ok) {
-			bf16_t* dkp = reinterpret_cast<bf16_t*>(a.dk) + ((int64_t)b * a.Skv + key) * a.lddk + h * DH + 4 * g;
-			bf16_t* dvp = reinterpret_cast<bf16_t*>(a.dv) + ((int64_t)b * a.Skv + key) * a.lddv + h * DH + 4 * g;
+				for (int dt = 0; dt < 4; ++dt) {
+					bf16x4 kv, vv;
 #pragma unroll
-			for (int dt = 0; dt < 4; ++dt) {
-				bf16x4 kv, vv;
-#pragma unroll
-				for (int r = 0; r < 4; ++r) {
-					kv[r] = (bf16_t)dk[dt][r];
-					vv[r] = (bf16_t)dv[dt][r];
+					for (int r = 0; r < 4; ++r) {
+						kv[r] = (bf16_t)dk[dt][r];
+						vv[r] = (bf16_t)dv[dt][r];
+					}
+					*reinterpret_cast<bf16x4*>(dkp + 16 * dt) = kv;
+					*reinterpret_cast<bf16x4*>(dvp + 16 * dt) = vv;
 				}
-				*reinterpret_cast<bf16x4*>(dkp + 16 * dt) = kv;
-				*reinterpret_cast<bf16x4*>(dvp + 16 * dt) = vv;
 			}
 		}
 	}
 }
+
 
 // consecutive (batch, head) pairs per workgroup of the forward kernel: as many as still leave every CU a workgroup
 int heads_per_workgroup(int n_bh) {
@@ -467,16 +582,19 @@ int launch_dq(const AttnArgs& a, hipStream_t st) {
 	return VITK_OK;
 }
 template <int T2, bool DROP>
-int launch_dkv(const AttnArgs& a, hipStream_t st) {
-	const int nw = std::min(16, (a.Skv + 15) / 16);
-	const size_t lds = (size_t)2 * T2 * 32 * 128 + (size_t)3 * T2 * 32 * sizeof(float);
+int launch_dkv(const AttnArgs& a0, hipStream_t st) {
+	AttnArgs a = a0;
+	const int n_bh = a.B * a.n_head;
+	a.heads_per_wg = heads_per_workgroup(n_bh);
+	const int qp = T2 * 32, qf = (qp + 63) & ~63;
+	const size_t lds = (size_t)2 * (2 * qp * 128 + 2 * qf * 4) + (size_t)2 * qp * sizeof(uint32_t);
 	static bool attr = false;
 	if (!attr) {
 		hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_dkv_mfma_kernel<T2, DROP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 		if (e != hipSuccess) return VITK_ERR_HIP - (int)e;
 		attr = true;
 	}
-	hipLaunchKernelGGL((attn_bwd_dkv_mfma_kernel<T2, DROP>), dim3((unsigned)(a.B * a.n_head)), dim3(64 * nw), lds, st, a);
+	hipLaunchKernelGGL((attn_bwd_dkv_mfma_kernel<T2, DROP>), dim3((unsigned)vitk_cdiv(n_bh, a.heads_per_wg)), dim3(512), lds, st, a);
 	VITK_CHECK_LAUNCH();
 	return VITK_OK;
 }
@@ -515,7 +633,8 @@ bool vitk_attention_mfma_ok(const AttnArgs& a, int dtype) {
 
 int vitk_attention_mfma(const AttnArgs& a, bool bwd, hipStream_t st) {
 	if (!bwd) return run_fwd(a, st);
-	int rc = run_dq(a, st);
+	if (a.bwd_scratch == nullptr) return VITK_ERR_NULL;
+	int rc = run_dq(a, st);  // also leaves lse (log2 units) and delta per query row in the scratch
 	if (rc != VITK_OK) return rc;
 	return run_dkv(a, st);
 }

@@ -360,9 +360,10 @@ def attention_fwd(q, k, v, B, n_head, Sq, Skv, dh, scale=0.0, drop=(0.0, 0)):
 def attention_bwd(dout, q, k, v, out, lse, dq, dk, dv, B, n_head, Sq, Skv, dh, scale=0.0, drop=(0.0, 0)):
 	"""Writes dq/dk/dv (views with unit inner stride, e.g. column slices of one [rows, 3d] buffer)."""
 	assert dout.stride(1) == 1 and dout.stride(0) == out.stride(0)
+	scratch = torch.empty((2,) + tuple(lse.shape), dtype=torch.float32, device=lse.device)  # dQ pass -> dK/dV pass
 	L.check(L.load().vitk_attention_bwd_dropout(L.ptr(dout), L.ptr(q), L.ptr(k), L.ptr(v), L.ptr(out), L.ptr(lse), L.ptr(dq), L.ptr(dk), L.ptr(dv),
 		B, n_head, Sq, Skv, dh, q.stride(0), k.stride(0), v.stride(0), out.stride(0), dq.stride(0), dk.stride(0), dv.stride(0),
-		scale, float(drop[0]), int(drop[1]), L.dtype_code(q.dtype), L.stream()))
+		scale, float(drop[0]), int(drop[1]), L.ptr(scratch), L.dtype_code(q.dtype), L.stream()))
 
 
 def gated_act_fwd(u, F, act):
