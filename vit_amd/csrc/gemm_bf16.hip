@@ -121,7 +121,26 @@ struct BfArgs {
 	GemmDev g;
 	int tiles_m, tiles_n, splits, k_per_split;  // k_per_split is a multiple of BK
 	int vec4;                                    // epilogue may use 4-wide accesses
+	int dma;                                     // K-major x K-major, K % 64 == 0: operand tiles by LDS-DMA
 };
+
+typedef __attribute__((address_space(3))) void* lds_void_p;
+typedef const __attribute__((address_space(1))) void* gbl_void_p;
+
+// LDS-DMA of one 128 x 64 K-major operand tile (global_load_lds_dwordx4, no register staging and no ds_write): 16
+// pieces of 8 rows x 128 bytes, 4 per wave.  A wave-instruction writes its 64 x 16 bytes linearly, so the image's
+// chunk swizzle is applied to each lane's SOURCE address; rows past the end re-read the last row (never stored).
+__device__ __forceinline__ void dma_tile_k(char* tile, const bf16_t* __restrict__ base, int64_t ld, int64_t mn0, int64_t mn_total, int k0, int wave, int lane) {
+	const int r = lane >> 3, slot = lane & 7;
+#pragma unroll
+	for (int j = 0; j < 4; ++j) {
+		const int piece = 4 * wave + j;
+		int64_t row = mn0 + 8 * piece + r;
+		if (row > mn_total - 1) row = mn_total - 1;
+		const bf16_t* src = base + row * ld + k0 + 8 * (slot ^ r);
+		__builtin_amdgcn_global_load_lds((gbl_void_p)src, (lds_void_p)(tile + piece * 1024), 16, 0, 0);
+	}
+}
 
 template <typename TOUT>
 __device__ __forceinline__ void store_frag(const BfArgs& a, int64_t m, int64_t nb, f32x4 v) {
@@ -141,7 +160,7 @@ template <int ALAYOUT, int BLAYOUT, bool PATCH, typename TOUT>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(BfArgs a) {
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 	const GemmDev& g = a.g;
-	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 	const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
 
 	// XCD-aware, bijective remap of the linear workgroup id, then grouped (8 tile-rows) raster so that
@@ -174,22 +193,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(BfArgs a) {
 #pragma unroll
 		for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-	uint4 ra[4], rb[4];
-	load_tile<ALAYOUT, PATCH>(g, A, g.lda, m0, g.M, k_begin, k_end, ra, tid);
-	load_tile<BLAYOUT, false>(g, B, g.ldb, n0, g.N, k_begin, k_end, rb, tid);
-	store_tile<ALAYOUT>(smem, ra, tid);
-	store_tile<BLAYOUT>(smem + TILE_BYTES, rb, tid);
-	__syncthreads();
-
-	for (int t = 0; t < nt; ++t) {
-		const char* sa = smem + (t & 1) * STAGE_BYTES;
-		const char* sb = sa + TILE_BYTES;
-		const bool more = (t + 1 < nt);
-		if (more) {
-			const int k0 = k_begin + (t + 1) * BK;
-			load_tile<ALAYOUT, PATCH>(g, A, g.lda, m0, g.M, k0, k_end, ra, tid);
-			load_tile<BLAYOUT, false>(g, B, g.ldb, n0, g.N, k0, k_end, rb, tid);
-		}
+	auto mma_tile = [&](const char* sa, const char* sb) {
 #pragma unroll
 		for (int s = 0; s < 2; ++s) {
 			bf16x8 xf[4], wf[4];
@@ -202,12 +206,52 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(BfArgs a) {
 #pragma unroll
 				for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], acc[i][j], 0, 0, 0);
 		}
-		if (more) {
-			char* da = smem + ((t + 1) & 1) * STAGE_BYTES;
-			store_tile<ALAYOUT>(da, ra, tid);
-			store_tile<BLAYOUT>(da + TILE_BYTES, rb, tid);
+	};
+
+	bool by_dma = false;
+	if constexpr (ALAYOUT == VITK_K_MAJOR && BLAYOUT == VITK_K_MAJOR && !PATCH) by_dma = a.dma != 0;
+	if (by_dma) {
+		// one barrier per K tile: it retires this tile's DMA (the fence in front of it drains vmcnt) and tells that every
+		// wave is done with the other stage, which the next tile's DMA then overwrites
+		dma_tile_k(smem, A, g.lda, m0, g.M, k_begin, wave, lane);
+		dma_tile_k(smem + TILE_BYTES, B, g.ldb, n0, g.N, k_begin, wave, lane);
+		for (int t = 0; t < nt; ++t) {
+			__syncthreads();
+			const char* sa = smem + (t & 1) * STAGE_BYTES;
+			if (t + 1 < nt) {
+				char* da = smem + ((t + 1) & 1) * STAGE_BYTES;
+				const int k0 = k_begin + (t + 1) * BK;
+				dma_tile_k(da, A, g.lda, m0, g.M, k0, wave, lane);
+				dma_tile_k(da + TILE_BYTES, B, g.ldb, n0, g.N, k0, wave, lane);
+			}
+			mma_tile(sa, sa + TILE_BYTES);
 		}
+		__syncthreads();  // the epilogue image goes over the stages
+	} else {
+		uint4 ra[4], rb[4];
+		load_tile<ALAYOUT, PATCH>(g, A, g.lda, m0, g.M, k_begin, k_end, ra, tid);
+		load_tile<BLAYOUT, false>(g, B, g.ldb, n0, g.N, k_begin, k_end, rb, tid);
+		store_tile<ALAYOUT>(smem, ra, tid);
+		store_tile<BLAYOUT>(smem + TILE_BYTES, rb, tid);
 		__syncthreads();
+
+		for (int t = 0; t < nt; ++t) {
+			const char* sa = smem + (t & 1) * STAGE_BYTES;
+			const char* sb = sa + TILE_BYTES;
+			const bool more = (t + 1 < nt);
+			if (more) {
+				const int k0 = k_begin + (t + 1) * BK;
+				load_tile<ALAYOUT, PATCH>(g, A, g.lda, m0, g.M, k0, k_end, ra, tid);
+				load_tile<BLAYOUT, false>(g, B, g.ldb, n0, g.N, k0, k_end, rb, tid);
+			}
+			mma_tile(sa, sb);
+			if (more) {
+				char* da = smem + ((t + 1) & 1) * STAGE_BYTES;
+				store_tile<ALAYOUT>(da, ra, tid);
+				store_tile<BLAYOUT>(da + TILE_BYTES, rb, tid);
+			}
+			__syncthreads();
+		}
 	}
 
 	// Epilogue through LDS: every lane drops its 16 accumulator fragments into a [128][128] float image of the
@@ -317,6 +361,8 @@ int vitk_gemm_bf16_128(const vitk_gemm_desc& d, hipStream_t st) {
 		hipError_t e = hipMemset2DAsync(d.C, (size_t)d.ldc * sizeof(float), 0, (size_t)d.N * sizeof(float), (size_t)d.M, st);
 		if (e != hipSuccess) return VITK_ERR_HIP - (int)e;
 	}
+	static const bool no_dma = getenv("VITK_NO_DMA128") != nullptr;  // A-B switch
+	a.dma = !no_dma && d.patch_grid == 0 && d.a_layout == VITK_K_MAJOR && d.b_layout == VITK_K_MAJOR && d.K % BK == 0 && d.M >= 1 && d.N >= 1;
 	dim3 grid((unsigned)tiles, (unsigned)a.splits);
 	const bool patch = d.patch_grid > 0;
 	if (patch) return launch<VITK_K_MAJOR, VITK_K_MAJOR, true>(a, d.out_dtype, grid, st);
