@@ -412,6 +412,32 @@ def conv_embedding_fwd(x, sd, prefix, stride, padding, training=True):
 	return y.reshape(b, c, h * w).transpose(1, 2)
 
 
+def mbconv_act(activation):
+	"""The activation MBConv really applies (layers/conv.py:12-17): the `if gelu / if silu / else` chain there has no
+	`elif`, so "gelu" falls through to the final `else` and becomes ReLU; only "silu" is kept."""
+	return "silu" if activation.lower() == "silu" else "relu"
+
+
+def mbconv_fwd(x, sd, prefix, stride, activation, training=True):
+	"""MBConv (layers/conv.py:20-44): Conv2d 1x1 -> BatchNorm2d -> act -> depthwise Conv2d 3x3 (stride, pad 1) ->
+	BatchNorm2d -> act -> Conv2d 1x1 -> BatchNorm2d, plus the input when stride == 1 and the channel counts agree.
+	x: [B, C, H, W].  State-dict keys are those of its nn.Sequential: conv.0 / conv.1 / conv.3 / conv.4 / conv.6 / conv.7."""
+	act = mbconv_act(activation)
+	c = prefix + "conv."
+
+	def bn(y, i):
+		return batchnorm2d_fwd(y, sd[f"{c}{i}.weight"], sd[f"{c}{i}.bias"], sd[f"{c}{i}.running_mean"], sd[f"{c}{i}.running_var"], training)[0]
+	h = conv2d_fwd(x, sd[c + "0.weight"], 1, 0)
+	h = act_fwd(bn(h, 1), act)
+	h = conv2d_fwd(h, sd[c + "3.weight"], stride, 1, groups=h.shape[1])
+	h = act_fwd(bn(h, 4), act)
+	h = conv2d_fwd(h, sd[c + "6.weight"], 1, 0)
+	h = bn(h, 7)
+	if stride == 1 and x.shape[1] == h.shape[1]:
+		h = x + h
+	return h
+
+
 def tokens_to_nchw(x, h, w):
 	b, n, c = x.shape
 	return x.transpose(1, 2).reshape(b, c, h, w)

@@ -166,3 +166,21 @@ def test_adamw():
 	for step in range(3):
 		p, m, v = O.adamw_step(p, g[f"g{step}"], m, v, step + 1, meta["lr"], *meta["betas"], meta["eps"], meta["weight_decay"])
 		assert relerr(p, g[f"p{step + 1}"]) < 1e-5
+
+
+@pytest.mark.parametrize("case", ["res_silu", "down_gelu", "wide_relu"])
+@pytest.mark.parametrize("mode", ["train", "eval"])
+def test_mbconv(case, mode):
+	"""MBConv (layers/conv.py:5-44), incl. its activation quirk ("gelu" runs as ReLU) and the residual rule."""
+	g, meta = load_golden("mbconv")
+	c = sub(g, f"{case}/{mode}")
+	ci, co, stride, expand, act, hw = meta["cases"][case]
+	sd = sub(c, "sd")
+	x = c["x"].clone().requires_grad_(True)
+	leaf = {kk: v.clone().requires_grad_(v.is_floating_point() and "running" not in kk) for kk, v in sd.items()}
+	y = O.mbconv_fwd(x, leaf, "", stride, act, training=(mode == "train"))
+	assert relerr(y, c["y"]) < TOL
+	y.backward(c["dy"])
+	assert relerr(x.grad, c["dx"]) < 2 * TOL
+	for kk, v in sub(c, "grad").items():
+		assert relerr(leaf[kk].grad, v) < 2 * TOL, kk

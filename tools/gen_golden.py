@@ -54,15 +54,57 @@ def model_fixture(model, x, y, criterion, extra=None):
 	return arrays
 
 
+MBCONV_CASES = {"res_silu": (16, 16, 1, 4, "silu", 8), "down_gelu": (16, 32, 2, 4, "gelu", 7), "wide_relu": (8, 24, 1, 2, "relu", 6)}
+
+
+def mbconv_fixture(args):
+	"""MBConv (layers/conv.py:5-44): 1x1 expand -> BN -> act -> depthwise 3x3 -> BN -> act -> 1x1 project -> BN
+	(+ input when stride 1 and equal channels), train and eval."""
+	from layers.conv import MBConv
+	g = torch.Generator().manual_seed(11)
+	arrays = {}
+	for nm, (ci, co, stride, expand, act, hw) in MBCONV_CASES.items():
+		for training in (True, False):
+			torch.manual_seed(5)
+			m = MBConv(ci, co, stride=stride, expand_ratio=expand, activation=act)
+			with torch.no_grad():
+				for mod in m.modules():
+					if isinstance(mod, nn.BatchNorm2d):
+						c = mod.num_features
+						mod.running_mean.copy_(0.1 * torch.randn(c, generator=g))
+						mod.running_var.copy_(0.5 + torch.rand(c, generator=g))
+						mod.weight.add_(0.2 * torch.randn(c, generator=g))
+						mod.bias.add_(0.2 * torch.randn(c, generator=g))
+			m.train(training)
+			tag = f"{nm}/{'train' if training else 'eval'}"
+			for kk, v in m.state_dict().items():
+				arrays[f"{tag}/sd/{kk}"] = np_(v)
+			x = torch.randn(3, ci, hw, hw, generator=g).requires_grad_(True)
+			yv = m(x)
+			dy = torch.randn(yv.shape, generator=g)
+			yv.backward(dy)
+			arrays[f"{tag}/x"] = np_(x); arrays[f"{tag}/y"] = np_(yv); arrays[f"{tag}/dy"] = np_(dy); arrays[f"{tag}/dx"] = np_(x.grad)
+			for kk, pp in m.named_parameters():
+				arrays[f"{tag}/grad/{kk}"] = np_(pp.grad)
+			for kk, v in m.state_dict().items():
+				if "running_" in kk:
+					arrays[f"{tag}/sd_after/{kk}"] = np_(v)
+	save(args.out, "mbconv", arrays, {"kind": "mbconv", "cases": {k: list(v) for k, v in MBCONV_CASES.items()}})
+
+
 def main():
 	ap = argparse.ArgumentParser()
 	ap.add_argument("--reference", default="/root/reference")
 	ap.add_argument("--out", default="tests/golden")
+	ap.add_argument("--only", default="", help="generate only this fixture (currently: mbconv)")
 	args = ap.parse_args()
 	sys.path.insert(0, args.reference)
 	os.makedirs(args.out, exist_ok=True)
 	torch.set_num_threads(4)
 
+	if args.only == "mbconv":
+		mbconv_fixture(args)
+		return
 	from config import ViTConfig, CvTConfig
 	from layers.attention import MHA, ConvAttention
 	from layers.embeddings import ConvEmbedding, patchify

@@ -1039,6 +1039,100 @@ class ConvAttentionFn(torch.autograd.Function):
 			grad_as(dck, ck), grad_as(dcv, cv), grad_as(dwo, wo), grad_as(dbo, bo), None)
 
 
+class MBConvFn(torch.autograd.Function):
+	"""MBConv (layers/conv.py:20-44 of the reference) on token-major activations: Conv2d 1x1 -> BatchNorm2d -> act ->
+	depthwise Conv2d 3x3 (stride, pad 1) -> BatchNorm2d -> act -> Conv2d 1x1 -> BatchNorm2d (+ input).  NCHW in and out
+	as in the reference; inside, the 1x1 convolutions are MFMA GEMMs over [B*H*W, C] rows, the depthwise convolution
+	and the BatchNorms run on the same rows, and the NCHW <-> rows gathers are the k = 1 cases of im2col / col2im."""
+
+	@staticmethod
+	def forward(ctx, x, w1, g1, b1, rm1, rv1, wd, g2, b2, rm2, rv2, w3, g3, b3, rm3, rv3, cfg):
+		stride, act, use_res, eps, momentum, training = cfg
+		L.require_gpu(x, w1)
+		lib = L.load()
+		dt = compute_dtype(x)
+		dtc = L.dtype_code(dt)
+		xc = cast(x, dt).contiguous()
+		Bn, Cin, H, W = xc.shape
+		hid, Cout = w1.shape[0], w3.shape[0]
+		R = Bn * H * W
+		t0 = torch.empty((R, Cin), dtype=dt, device=x.device)
+		L.check(lib.vitk_im2col(L.ptr(xc), L.ptr(t0), Bn, Cin, H, W, 1, 1, 0, 0, dtc, L.stream()))
+
+		def bn(h, g, b, rm, rv):
+			y = torch.empty_like(h)
+			mean = torch.empty(h.shape[1], dtype=torch.float32, device=h.device)
+			rstd = torch.empty(h.shape[1], dtype=torch.float32, device=h.device)
+			L.check(lib.vitk_batchnorm_fwd(L.ptr(h), L.ptr(f32(g)), L.ptr(f32(b)), L.ptr(rm), L.ptr(rv), L.ptr(y), L.ptr(mean), L.ptr(rstd),
+				h.shape[0], h.shape[1], eps, momentum, int(training), dtc, L.stream()))
+			return y, mean, rstd
+
+		def act_fwd(u):
+			a = torch.empty_like(u)
+			L.check(lib.vitk_act_fwd(L.ptr(u), L.ptr(a), u.numel(), act, dtc, L.stream()))
+			return a
+		h1 = linear_fwd(t0, weight_as(w1, dt).reshape(hid, Cin))
+		n1, m1, r1 = bn(h1, g1, b1, rm1, rv1)
+		a1 = act_fwd(n1)
+		h2, S2 = dwconv_fwd(a1, weight_as(wd, dt), Bn, H, W, hid, 3, stride, 1)
+		n2, m2, r2 = bn(h2, g2, b2, rm2, rv2)
+		a2 = act_fwd(n2)
+		h3 = linear_fwd(a2, weight_as(w3, dt).reshape(Cout, hid))
+		n3, m3, r3 = bn(h3, g3, b3, rm3, rv3)
+		if use_res:
+			n3 = scale_residual(n3, t0, None)
+		Ho, Wo = _conv_out(H, 3, stride, 1), _conv_out(W, 3, stride, 1)
+		y = torch.empty((Bn, Cout, Ho, Wo), dtype=dt, device=x.device)
+		L.check(lib.vitk_col2im(L.ptr(n3), L.ptr(y), Bn, Cout, Ho, Wo, 1, 1, 0, 0, dtc, L.stream()))
+		ctx.save_for_backward(t0, h1, n1, a1, h2, n2, a2, h3, m1, r1, m2, r2, m3, r3, w1, wd, w3, g1, g2, g3)
+		ctx.meta = (x.shape, x.dtype, (b1, b2, b3), cfg, dt, (Bn, Cin, H, W, hid, Cout, Ho, Wo))
+		return y
+
+	@staticmethod
+	def backward(ctx, dy):
+		t0, h1, n1, a1, h2, n2, a2, h3, m1, r1, m2, r2, m3, r3, w1, wd, w3, g1, g2, g3 = ctx.saved_tensors
+		xshape, xdtype, (b1, b2, b3), cfg, dt, (Bn, Cin, H, W, hid, Cout, Ho, Wo) = ctx.meta
+		stride, act, use_res, eps, momentum, training = cfg
+		lib = L.load()
+		dtc = L.dtype_code(dt)
+		dyc = cast(dy, dt).contiguous()
+		d3 = torch.empty((Bn * Ho * Wo, Cout), dtype=dt, device=dy.device)
+		L.check(lib.vitk_im2col(L.ptr(dyc), L.ptr(d3), Bn, Cout, Ho, Wo, 1, 1, 0, 0, dtc, L.stream()))
+
+		def bn_bwd(dn, h, g, mean, rstd):
+			dh = torch.empty_like(h)
+			dg = torch.empty(h.shape[1], dtype=torch.float32, device=h.device)
+			db = torch.empty(h.shape[1], dtype=torch.float32, device=h.device)
+			L.check(lib.vitk_batchnorm_bwd(L.ptr(dn), L.ptr(h), L.ptr(f32(g)), L.ptr(mean), L.ptr(rstd), L.ptr(dh), L.ptr(dg), L.ptr(db),
+				h.shape[0], h.shape[1], int(training), dtc, L.stream()))
+			return dh, dg, db
+
+		def act_bwd(da, pre):
+			du = torch.empty_like(pre)
+			L.check(lib.vitk_act_bwd(L.ptr(da), L.ptr(pre), L.ptr(du), pre.numel(), act, dtc, L.stream()))
+			return du
+		dh3, dg3, db3 = bn_bwd(d3, h3, g3, m3, r3)
+		dw3 = linear_wgrad(dh3, a2).reshape(w3.shape)
+		da2 = linear_dgrad(dh3, weight_as(w3, dt).reshape(Cout, hid))
+		dn2 = act_bwd(da2, n2)
+		dh2, dg2, db2 = bn_bwd(dn2, h2, g2, m2, r2)
+		da1, dwd = dwconv_bwd(dh2, a1, weight_as(wd, dt), Bn, H, W, hid, 3, stride, 1)
+		dn1 = act_bwd(da1, n1)
+		dh1, dg1, db1 = bn_bwd(dn1, h1, g1, m1, r1)
+		dw1 = linear_wgrad(dh1, t0).reshape(w1.shape)
+		dx = None
+		if ctx.needs_input_grad[0]:
+			dt0 = linear_dgrad(dh1, weight_as(w1, dt).reshape(hid, Cin))
+			if use_res:
+				dt0 = scale_residual(dt0, d3, None)
+			dx = torch.empty(xshape, dtype=dt, device=dy.device)
+			L.check(lib.vitk_col2im(L.ptr(dt0), L.ptr(dx), Bn, Cin, H, W, 1, 1, 0, 0, dtc, L.stream()))
+			if dx.dtype != xdtype:
+				dx = cast(dx, xdtype)
+		return (dx, grad_as(dw1, w1), grad_as(dg1, g1), grad_as(db1, b1), None, None, grad_as(dwd, wd), grad_as(dg2, g2), grad_as(db2, b2), None, None,
+			grad_as(dw3, w3), grad_as(dg3, g3), grad_as(db3, b3), None, None, None)
+
+
 class MeanPoolFn(torch.autograd.Function):
 	"""x.mean(dim=1) over tokens (models/cvt.py:105 of the reference)."""
 
