@@ -25,6 +25,10 @@ CONFIGS = {
 	# BASELINE config 1 geometry (ViT-Tiny patch 4 on 32x32)
 	"vit_tiny": dict(d_model=192, n_head=3, n_block=12, n_patch=8, d_ff=768, out_d=10, chw=(3, 32, 32), batch=512),
 }
+# BASELINE config 3: the reference's CvTConfig defaults (config.py:53-98: CvT-13 geometry 64/192/384, depths 1/2/10, heads 1/3/6,
+# SiLU, RMSNorm) on 32x32 inputs with 10 classes
+CVT = dict(chw=(3, 32, 32), out_d=10, batch=256, use_layer_scale=False, activation="silu",
+	s1=(7, 4, 2, 64, 1, 1, 4.0, 3, 1, 1), s2=(3, 2, 1, 192, 2, 3, 4.0, 3, 2, 1), s3=(3, 2, 1, 384, 10, 6, 4.0, 3, 2, 1))
 PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak of one MI355X
 
 
@@ -50,6 +54,19 @@ def make_config(c, dropout=0.0):
 	for k in ("d_model", "n_head", "n_block", "n_patch", "d_ff", "out_d", "chw"):
 		setattr(Cfg, k, c[k])
 	Cfg.dropout = dropout
+	return Cfg()
+
+
+def make_cvt_config(dropout=0.0):
+	from vit_amd.layers import RMSNorm
+
+	class Cfg:
+		norm = RMSNorm
+	Cfg.chw, Cfg.out_d, Cfg.use_layer_scale, Cfg.activation, Cfg.dropout = CVT["chw"], CVT["out_d"], CVT["use_layer_scale"], CVT["activation"], dropout
+	names = ("emb_kernel", "emb_stride", "emb_pad", "emb_dim", "depth", "heads", "mlp_ratio", "qkv_kernel", "qkv_stride", "qkv_pad")
+	for s_ in (1, 2, 3):
+		for n, v in zip(names, CVT[f"s{s_}"]):
+			setattr(Cfg, f"s{s_}_{n}", v)
 	return Cfg()
 
 
@@ -85,7 +102,7 @@ def main():
 	ap.add_argument("--warmup", type=int, default=3)
 	ap.add_argument("--graph", action="store_true", help="capture the training step into a HIP graph and replay it (single GPU)")
 	ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the config's)")
-	ap.add_argument("--config", default="vit_b16", choices=sorted(CONFIGS))
+	ap.add_argument("--config", default="vit_b16", choices=sorted(CONFIGS) + ["cvt"])
 	ap.add_argument("--dropout", type=float, default=0.0, help="config.dropout (attention-probability, branch and feed-forward dropouts)")
 	ap.add_argument("--no-cpu-baseline", action="store_true")
 	ap.add_argument("--no-kernel-timing", action="store_true")
@@ -105,10 +122,15 @@ def main():
 	from vit_amd import dp, ops
 	from vit_amd.models import ViT
 
-	c = CONFIGS[args.config]
+	is_cvt = args.config == "cvt"
+	c = CVT if is_cvt else CONFIGS[args.config]
 	batch = args.batch or c["batch"]
 	torch.manual_seed(0)
-	model = ViT(make_config(c, args.dropout)).to(dev)
+	if is_cvt:
+		from vit_amd.models import CvT
+		model = CvT(make_cvt_config(args.dropout)).to(dev)
+	else:
+		model = ViT(make_config(c, args.dropout)).to(dev)
 	trainer = dp.Trainer(model, lr=1e-3, weight_decay=0.05)
 	g = torch.Generator(device="cpu").manual_seed(1234 + rank)
 	x = torch.randn(batch, *c["chw"], generator=g).to(dev)
@@ -157,7 +179,15 @@ def main():
 	final_loss = loss.item()
 	assert final_loss == final_loss, "loss is NaN"
 
-	if rank == 0:
+	if rank == 0 and is_cvt:
+		# secondary configuration (BASELINE config 3): throughput only, no FLOP model / roofline for it
+		print(json.dumps({"metric": "train images/sec (node) CvT-13 geometry 32x32 bf16", "value": round(batch * world * args.steps / elapsed, 2), "unit": "images/sec",
+			"n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True,
+			"scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+			"config": {"workload": "cvt: CvTConfig defaults (64/192/384, depths 1/2/10, heads 1/3/6, silu, RMSNorm) at 32x32, 10 classes, fwd+CE+bwd+AdamW",
+				"global_batch": batch * world, "per_gpu_batch": batch, "parallelism": f"dp{world}", "hip_graph": bool(args.graph), "dropout": args.dropout},
+			"final_loss": round(final_loss, 4)}), flush=True)
+	elif rank == 0:
 		value = batch * world * args.steps / elapsed
 		flops_img = train_flops_per_image(c)
 		out = {
