@@ -64,31 +64,47 @@ __global__ __launch_bounds__(256) void dwconv_bwd_dx_kernel(const T* __restrict_
 	}
 }
 
-// dw[c, kh, kw] += sum over (b, ho, wo) of dy * x.  grid.x: channel blocks of 64, grid.y: slabs of output positions.
+// dw[c, kh, kw] += sum over (b, ho, wo) of dy * x.  Block = 64 channels x DW_TY position lanes; grid.x: channel blocks of
+// 64, grid.y: slabs of output positions.  The position lanes of a block are summed through LDS and the block issues
+// one float atomic per (channel, tap), so an address sees gridDim.y atomics.
+constexpr int DW_TY = 16;
 template <typename T>
-__global__ __launch_bounds__(64) void dwconv_bwd_dw_kernel(const T* __restrict__ dy, const T* __restrict__ x, float* dw, int64_t B, int H, int W, int C, int ks,
+__global__ __launch_bounds__(64 * DW_TY) void dwconv_bwd_dw_kernel(const T* __restrict__ dy, const T* __restrict__ x, float* dw, int64_t B, int H, int W, int C, int ks,
 	int stride, int pad, int Ho, int Wo) {
-	const int c = blockIdx.x * 64 + threadIdx.x;
-	if (c >= C) return;
+	__shared__ float red[DW_TY][25][64];
+	const int tx = threadIdx.x, ty = threadIdx.y;
+	const int c = blockIdx.x * 64 + tx;
 	const int64_t npos = B * Ho * Wo;
 	float acc[25];  // ks <= 5
 	for (int j = 0; j < ks * ks; ++j) acc[j] = 0.f;
-	for (int64_t pidx = blockIdx.y; pidx < npos; pidx += gridDim.y) {
-		const int wo = (int)(pidx % Wo);
-		const int ho = (int)((pidx / Wo) % Ho);
-		const int64_t b = pidx / ((int64_t)Wo * Ho);
-		const float g = to_f32<T>(dy[pidx * C + c]);
-		for (int kh = 0; kh < ks; ++kh) {
-			const int h = ho * stride - pad + kh;
-			if (h < 0 || h >= H) continue;
-			for (int kw = 0; kw < ks; ++kw) {
-				const int ww = wo * stride - pad + kw;
-				if (ww < 0 || ww >= W) continue;
-				acc[kh * ks + kw] += g * to_f32<T>(x[((b * H + h) * W + ww) * C + c]);
+	if (c < C) {
+		for (int64_t pidx = (int64_t)blockIdx.y * DW_TY + ty; pidx < npos; pidx += (int64_t)gridDim.y * DW_TY) {
+			const int wo = (int)(pidx % Wo);
+			const int ho = (int)((pidx / Wo) % Ho);
+			const int64_t b = pidx / ((int64_t)Wo * Ho);
+			const float g = to_f32<T>(dy[pidx * C + c]);
+			for (int kh = 0; kh < ks; ++kh) {
+				const int h = ho * stride - pad + kh;
+				if (h < 0 || h >= H) continue;
+				for (int kw = 0; kw < ks; ++kw) {
+					const int ww = wo * stride - pad + kw;
+					if (ww < 0 || ww >= W) continue;
+					acc[kh * ks + kw] += g * to_f32<T>(x[((b * H + h) * W + ww) * C + c]);
+				}
 			}
 		}
 	}
-	for (int j = 0; j < ks * ks; ++j) atomicAdd(&dw[c * ks * ks + j], acc[j]);
+	for (int j = 0; j < ks * ks; ++j) red[ty][j][tx] = acc[j];
+	__syncthreads();
+	// thread (tx, ty) sums tap j = ty, ty + DW_TY, ... of channel tx over the position lanes
+	if (c < C) {
+		for (int j = ty; j < ks * ks; j += DW_TY) {
+			float v = 0.f;
+#pragma unroll
+			for (int l = 0; l < DW_TY; ++l) v += red[l][j][tx];
+			atomicAdd(&dw[c * ks * ks + j], v);
+		}
+	}
 }
 
 // ---- im2col / col2im -----------------------------------------------------------------------------------------
@@ -299,8 +315,8 @@ extern "C" int vitk_dwconv_bwd(const void* dy, const void* x, const void* w, voi
 			(int)C, (int)ks, (int)stride, (int)pad, (int)Ho, (int)Wo);
 		VITK_CHECK_LAUNCH();
 		const unsigned gx = (unsigned)vitk_cdiv(C, 64);
-		const unsigned gy = (unsigned)std::max<int64_t>(1, std::min<int64_t>(B * Ho * Wo, 2048 / gx));
-		hipLaunchKernelGGL((dwconv_bwd_dw_kernel<T>), dim3(gx, gy), dim3(64), 0, st, (const T*)dy, (const T*)x, dw, B, (int)H, (int)W, (int)C, (int)ks, (int)stride,
+		const unsigned gy = (unsigned)std::max<int64_t>(1, std::min<int64_t>(vitk_cdiv(B * Ho * Wo, 4 * DW_TY), std::max<int64_t>(1, 512 / gx)));
+		hipLaunchKernelGGL((dwconv_bwd_dw_kernel<T>), dim3(gx, gy), dim3(64, DW_TY), 0, st, (const T*)dy, (const T*)x, dw, B, (int)H, (int)W, (int)C, (int)ks, (int)stride,
 			(int)pad, (int)Ho, (int)Wo);
 		VITK_CHECK_LAUNCH();
 		return VITK_OK;

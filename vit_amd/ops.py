@@ -920,6 +920,13 @@ class ConvEmbedFn(torch.autograd.Function):
 		cols = torch.empty((rows, K), dtype=dt, device=x.device)
 		L.check(lib.vitk_im2col(L.ptr(xc), L.ptr(cols), Bn, C, H, W, ks, stride, pad, tokens_in, dtc, L.stream()))
 		w2 = weight_as(conv_w, dt).reshape(Cout, K)
+		if dt == torch.bfloat16 and K % 8 != 0:
+			# K = 3 * 7 * 7 = 147 for the first CvT stage: zero columns up to a multiple of 8 put all three GEMMs of this layer
+			# on the bf16 MFMA kernels (the weight gradient is a [64, 147] x 16384-deep product: 3 workgroups and no K split
+			# on the generic kernel)
+			Kp = (K + 7) // 8 * 8
+			cols = torch.nn.functional.pad(cols, (0, Kp - K))
+			w2 = torch.nn.functional.pad(w2, (0, Kp - K))
 		y0 = linear_fwd(cols, w2)
 		y = torch.empty_like(y0)
 		save_mean = torch.empty(Cout, dtype=torch.float32, device=x.device)
@@ -944,11 +951,18 @@ class ConvEmbedFn(torch.autograd.Function):
 		dbeta = torch.empty(Cout, dtype=torch.float32, device=dy.device)
 		L.check(lib.vitk_batchnorm_bwd(L.ptr(dy2), L.ptr(y0), L.ptr(f32(bn_w)), L.ptr(save_mean), L.ptr(save_rstd), L.ptr(dy0), L.ptr(dgamma), L.ptr(dbeta),
 			rows, Cout, int(training), dtc, L.stream()))
-		dw = linear_wgrad(dy0, cols).reshape(conv_w.shape)
+		K = conv_w[0].numel()
+		Kp = cols.shape[1]  # K, or K padded with zero columns
+		dw = linear_wgrad(dy0, cols)
+		dw = (dw[:, :K] if Kp != K else dw).reshape(conv_w.shape)
 		dx = None
 		if ctx.needs_input_grad[0]:
 			w2 = weight_as(conv_w, dt).reshape(Cout, -1)
+			if Kp != K:
+				w2 = torch.nn.functional.pad(w2, (0, Kp - K))
 			dcols = linear_dgrad(dy0, w2)
+			if Kp != K:
+				dcols = dcols[:, :K].contiguous()
 			dx = torch.empty(xshape, dtype=dt, device=dy.device)
 			L.check(lib.vitk_col2im(L.ptr(dcols), L.ptr(dx), Bn, C, H, W, ks, stride, pad, tokens_in, dtc, L.stream()))
 			if dx.dtype != xdtype:
