@@ -94,3 +94,52 @@ def test_buckets_reduced_once_after_their_last_write(gpu, bucket_bytes, monkeypa
 	for (n, p), (_, q) in zip(ref.named_parameters(), model2.named_parameters()):
 		assert relerr(q.grad, p.grad.cpu().double()) < 1e-4, n
 	ops.clear_grad_sinks()
+
+
+def test_checkpoint_resume_continues_the_run(gpu, tmp_path):
+	"""Save after two steps in the reference's checkpoint format (train.py:121-157 there), load into a fresh model +
+	trainer, take a third step on both: the loaded state is bit-identical, the step after it agrees to float
+	rounding (the norm-parameter gradients are summed with float atomics, whose order varies between runs).  The optimizer entry of the file also
+	loads into a stock torch.optim.AdamW with the reference's parameter groups."""
+	from vit_amd import checkpoint as ck, dp, ops
+	ops.clear_grad_sinks()
+	g = torch.Generator().manual_seed(3)
+	x = torch.randn(8, 3, 16, 16, generator=g).to(gpu)
+	y = torch.randint(0, 10, (8,), generator=g).to(gpu)
+
+	def one_step(model, tr):
+		tr.zero_grad()
+		with torch.autocast("cuda", dtype=torch.bfloat16):
+			ops.cross_entropy(model(x), y).backward()
+		tr.step()
+
+	a = _model(gpu)
+	ta = dp.Trainer(a, lr=1e-2, weight_decay=0.05)
+	one_step(a, ta)
+	one_step(a, ta)
+	path = str(tmp_path / "run.pt")
+	ck.save_checkpoint(path, a, ta, epoch=4, best_val_loss=1.5)
+	b = _model(gpu)
+	with torch.no_grad():
+		for p in b.parameters():
+			p.add_(1.0)  # make sure the load is what sets them
+	tb = dp.Trainer(b, lr=1.0, weight_decay=0.0)
+	epoch, best = ck.load_checkpoint(path, b, tb, map_location=gpu)
+	assert (epoch, best) == (5, 1.5) and tb.opt.step_count == 2 and tb.opt.lr == 1e-2 and tb.opt.weight_decay == 0.05
+	assert torch.equal(tb.flat.param, ta.flat.param) and torch.equal(tb.opt.m, ta.opt.m) and torch.equal(tb.opt.v, ta.opt.v)
+	assert torch.equal(tb.opt.shadow, ta.opt.shadow)  # (the transposed copies are covered by the next step: the input-gradient GEMMs read them)
+	one_step(a, ta)
+	one_step(b, tb)
+	assert tb.opt.step_count == 3
+	for got, want in ((tb.flat.param, ta.flat.param), (tb.opt.m, ta.opt.m), (tb.opt.v, ta.opt.v)):
+		assert torch.allclose(got, want, rtol=1e-4, atol=1e-7), float((got - want).abs().max())
+	# the same file feeds a stock AdamW over the reference's two groups
+	sd = torch.load(path, weights_only=True)
+	c = _model("cpu")
+	c.load_state_dict(sd["model_state_dict"])
+	dec = [p for n, p in c.named_parameters() if not dp.no_decay(n)]
+	nod = [p for n, p in c.named_parameters() if dp.no_decay(n)]
+	opt = torch.optim.AdamW([{"params": dec, "weight_decay": 0.05}, {"params": nod, "weight_decay": 0.0}], lr=1e-2)
+	opt.load_state_dict(sd["optimizer_state_dict"])
+	assert all(float(s["step"]) == 2.0 for s in opt.state.values()) and len(opt.state) == len(dec) + len(nod)
+	ops.clear_grad_sinks()

@@ -21,10 +21,11 @@ from . import ops
 
 
 def no_decay(name):
-	"""Parameter-group rule of the reference (utils.py:102-121 there): names containing 'bias', 'norm' or
-	'layerscale' get no weight decay.  (The block's LayerScale parameters are called '*_layer_scale', which
-	that substring test does not match, so they ARE decayed — reproduced as is.)"""
-	return ("bias" in name) or ("norm" in name) or ("layerscale" in name)
+	"""Parameter-group rule of the reference (utils.py:102-121 there): names ending in 'bias' or containing 'norm' or
+	'layerscale' (case-insensitive) get no weight decay.  (The block's LayerScale parameters are called
+	'*_layer_scale', which that substring test does not match, so they ARE decayed — reproduced as is.)"""
+	low = name.lower()
+	return name.endswith("bias") or ("norm" in low) or ("layerscale" in low)
 
 
 class FlatModel:
@@ -170,6 +171,15 @@ class FlatAdamW:
 	def _refresh_transposed(self):
 		if self.shadow is not None and self.t_tiles.shape[0] > 0:
 			L.check(L.load().vitk_transpose_batched(L.ptr(self.t_items), L.ptr(self.t_tiles), self.t_tiles.shape[0], L.BF16, L.stream()))
+
+	def refresh_copies(self):
+		"""Re-derive the bfloat16 and transposed copies after the float32 parameters were written from outside
+		(load_state_dict, a broadcast)."""
+		if self.shadow is not None:
+			L.check(L.load().vitk_cast(L.ptr(self.flat.param), L.ptr(self.shadow), self.flat.numel, L.F32, L.BF16, L.stream()))
+			self._refresh_transposed()
+		ops.invalidate_casts()
+		ops.weights_changed()
 
 	def set_step(self, n):
 		"""Set the number of steps taken so far (resuming from a checkpoint)."""
