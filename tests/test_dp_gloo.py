@@ -74,6 +74,41 @@ def test_bucketed_allreduce_two_ranks(bucket_bytes):
 		assert ret[0][1] == 1
 
 
+def _bcast_worker(rank, world, port, ret):
+	sys.path.insert(0, ROOT)
+	os.environ["MASTER_ADDR"] = "127.0.0.1"
+	os.environ["MASTER_PORT"] = str(port)
+	dist.init_process_group("gloo", rank=rank, world_size=world)
+	from vit_amd import dp
+	torch.manual_seed(100 + rank)  # replicas start DIFFERENT
+	model = nn.Sequential(nn.Linear(6, 8), nn.BatchNorm1d(8), nn.Linear(8, 3))
+	model[2].bias.requires_grad_(False)  # frozen: not in the flat buffer
+	with torch.no_grad():
+		model[1].running_mean.add_(float(rank) + 0.5)
+	flat = dp.FlatModel(model)
+	dp.broadcast_replica(flat)
+	inside = all(flat.param.data_ptr() <= p.data_ptr() < flat.param.data_ptr() + 4 * flat.numel for p in flat.params)
+	ret[rank] = ({k: v.clone() for k, v in model.state_dict().items()}, inside)
+	dist.destroy_process_group()
+
+
+def test_replicas_start_from_rank0():
+	world = 2
+	port = 29500 + (os.getpid() % 1000) + 7
+	mgr = mp.Manager()
+	ret = mgr.dict()
+	mp.spawn(_bcast_worker, args=(world, port, ret), nprocs=world, join=True)
+	torch.manual_seed(100)
+	want = nn.Sequential(nn.Linear(6, 8), nn.BatchNorm1d(8), nn.Linear(8, 3))
+	with torch.no_grad():
+		want[1].running_mean.add_(0.5)
+	for rank in range(world):
+		sd, inside = ret[rank]
+		assert inside, "parameters must stay views of the flat buffer after the broadcast"
+		for k, v in want.state_dict().items():
+			assert torch.equal(sd[k], v), f"rank {rank}: {k} is not rank 0's"
+
+
 def test_flat_model_layout():
 	sys.path.insert(0, ROOT)
 	from vit_amd import dp

@@ -73,6 +73,21 @@ class FlatModel:
 				p.grad = self.grad[o:o + p.numel()].view(p.shape)
 
 
+def broadcast_replica(flat, src=0, process_group=None):
+	"""Every rank starts from rank `src`'s replica: ONE broadcast of the flat parameter buffer (the trainable parameters
+	are views into it), then the few tensors outside it (frozen parameters, BatchNorm statistics).  No-op in a single
+	process."""
+	if not (dist.is_initialized() and dist.get_world_size(process_group) > 1):
+		return
+	dist.broadcast(flat.param, src=src, group=process_group)
+	inside = {id(p) for p in flat.params}
+	for p in flat.module.parameters():
+		if id(p) not in inside:
+			dist.broadcast(p.data, src=src, group=process_group)
+	for b in flat.module.buffers():
+		dist.broadcast(b.data, src=src, group=process_group)
+
+
 class GradSync:
 	"""Bucketed all-reduce(sum) of FlatModel.grad, launched from autograd hooks during backward."""
 
@@ -203,12 +218,8 @@ class Trainer:
 	"""zero_grad -> forward/backward (caller) -> step, with gradient sync when torch.distributed is initialised."""
 
 	def __init__(self, module, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, bucket_bytes=48 << 20):
-		if dist.is_initialized() and dist.get_world_size() > 1:
-			for p in module.parameters():
-				dist.broadcast(p.data, src=0)
-			for b in module.buffers():
-				dist.broadcast(b.data, src=0)
 		self.flat = FlatModel(module, bucket_bytes)
+		broadcast_replica(self.flat)
 		self.sync = GradSync(self.flat)
 		self.opt = FlatAdamW(self.flat, lr, betas, eps, weight_decay)
 		# backward kernels that know about gradient sinks add straight into the flat gradient buffer (no temporary, no
