@@ -111,6 +111,14 @@ typedef struct vitk_gemm_desc {
 	                              atomics into C.  Contents are undefined afterwards; calls that share it must be
 	                              ordered on one stream. */
 	int64_t workspace_bytes;
+	float drop_p[2];           /* dropout fused into the epilogue (0 = off), nn.Dropout of layers/vit.py:17-23 and
+	                              layers/transformers.py:20-21: with VITK_EPI_ACT the activation output, with
+	                              VITK_EPI_RESIDUAL the branch value (acc + bias) before gamma and the residual add,
+	                              with VITK_EPI_ACTGRAD the incoming gradient (acc) are multiplied by the mask of
+	                              element m * N + n and by 1 / keep-probability; two entries = two stacked dropouts.
+	                              The mask is the one vitk_dropout(p, seed) applies to a contiguous [M, N] tensor.
+	                              Any other epilogue with drop_p != 0: VITK_ERR_UNSUPPORTED. */
+	uint64_t drop_seed[2];
 } vitk_gemm_desc;
 
 int vitk_gemm(const vitk_gemm_desc* desc, void* stream);

@@ -205,6 +205,42 @@ def _hash32(x):
 	return x
 
 
+def _splitmix64(z):
+	"""The 64-bit seed mixer applied on the host before the mask hash (plain Python integers modulo 2^64)."""
+	m = (1 << 64) - 1
+	z = (z + 0x9E3779B97F4A7C15) & m
+	z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & m
+	z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & m
+	return z ^ (z >> 31)
+
+
+def dropout_multiplier(seed, p, n):
+	"""nn.Dropout (layers/vit.py:17-23, layers/transformers.py:20-21) as the HIP kernels draw it, for a contiguous tensor of
+	n elements: float64 vector of 0 or 1 / (1 - p'), p' = p quantised to 1/65536.  Elements 2j and 2j+1 take the low and
+	high 16 bits of one 32-bit hash of (seed, j).  The streaming dropout kernels and the GEMM epilogues use this same
+	function (element index = row * N + column).  torch's Philox stream cannot be reproduced, so the tests hand THIS
+	mask to the reference arithmetic."""
+	import numpy as np
+	if p <= 0.0:
+		return torch.ones(n, dtype=torch.float64)
+	m = np.uint64(0xFFFFFFFF)
+	z = _splitmix64(int(seed) & ((1 << 64) - 1))
+	k0, k1 = np.uint64(z & 0xFFFFFFFF), np.uint64(z >> 32)
+	t = float(np.float32(p) * np.float32(65536.0) + np.float32(0.5))
+	thr = 65535 if t >= 65535.0 else (1 if t < 1.0 else int(t))
+	pair = np.arange((n + 1) // 2, dtype=np.uint64)
+	x = (pair & m) ^ k0
+	x ^= x >> np.uint64(16)
+	x = (x * np.uint64(0x7feb352d)) & m
+	x = (x + k1 + (pair >> np.uint64(32)) * np.uint64(0x9E3779B1)) & m
+	x ^= x >> np.uint64(15)
+	x = (x * np.uint64(0x846ca68b)) & m
+	x ^= x >> np.uint64(16)
+	bits = np.stack([x & np.uint64(0xFFFF), x >> np.uint64(16)], axis=1).reshape(-1)[:n]
+	keep = (bits >= np.uint64(thr)).astype(np.float64) * (65536.0 / (65536 - thr))
+	return torch.from_numpy(keep)
+
+
 def attn_dropout_keep(seed, p, B, H, Sq, Skv):
 	"""Keep mask of the attention-probability dropout (the `dropout_p` of F.scaled_dot_product_attention,
 	layers/attention.py:41,86), as the HIP kernels generate it: values 0 or 1/(1 - p'), shape [B, H, Sq, Skv], with

@@ -100,6 +100,58 @@ def test_gemm_epilogues(gpu, dtype, act):
 	assert relerr(du, (dyr @ w2r) * O.act_grad(pre.cpu().double(), act)) < TOL[dtype]
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("n,p", [(10, 0.3), (4097, 0.1), (200 * 256, 0.5), (7, 0.999)])
+def test_dropout_mask_matches_oracle(gpu, dtype, n, p):
+	"""The streaming dropout kernel draws exactly the mask the oracle restates (bit for bit), alone and stacked."""
+	from vit_amd import ops
+	x = torch.ones(n, device=gpu).to(dtype)
+	got = ops.dropout_add(x, None, p, 1234567)
+	want = O.dropout_multiplier(1234567, p, n)
+	assert torch.equal(got.cpu().double() != 0, want != 0)
+	assert relerr(got, want) < 5e-3 if dtype == torch.bfloat16 else relerr(got, want) < 1e-6
+	kept = float((want != 0).double().mean())
+	if n > 1000:
+		assert abs(kept - (1 - p)) < 0.03
+	got2 = ops.dropout_add(x, None, p, 1234567, 0.25, 99)
+	assert torch.equal(got2.cpu().double() != 0, (want != 0) & (O.dropout_multiplier(99, 0.25, n) != 0))
+	assert not torch.equal(O.dropout_multiplier(1234568, p, n) != 0, want != 0) or n < 16
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K", [(200, 256, 128), (4363, 3848, 128), (1024, 1024, 128), (300, 130, 72), (33, 7, 5)])
+def test_gemm_fused_dropout(gpu, dtype, M, N, K):
+	"""Dropout fused into the GEMM epilogues (activation output, branch before the residual add, gradient in front of
+	the activation derivative) uses the mask of the streaming kernel on element m * N + n: every kernel path (float32
+	MFMA, 128x128, 256x256 single-tile and persistent with ragged edges, unaligned and odd N)."""
+	from vit_amd import ops
+	import vit_amd._lib as L
+	if dtype == torch.float32 and M > 2000:
+		pytest.skip("large shapes are the bf16 kernels' cases")
+	x, xr = rnd((M, K), dtype, gpu, seed=1)
+	w, wr = rnd((N, K), dtype, gpu, 0.1, seed=2)
+	bias = torch.randn(N, generator=torch.Generator().manual_seed(3))
+	d1, d2 = (0.3, 4242), (0.1, 77)
+	m1 = O.dropout_multiplier(d1[1], d1[0], M * N).reshape(M, N)
+	m12 = m1 * O.dropout_multiplier(d2[1], d2[0], M * N).reshape(M, N)
+	y, pre = ops.linear_fwd(x, w, bias.to(gpu), act=L.ACT_CODES["gelu"], save_pre=True, drop=(d1,))
+	pre_ref = xr @ wr.t() + bias.double()
+	assert relerr(pre, pre_ref) < TOL[dtype]
+	assert torch.equal(y.cpu() == 0, (m1 == 0) | (y.cpu() == 0)) and relerr(y, O.act_fwd(pre.cpu().double(), "gelu") * m1) < TOL[dtype]
+	res, rr = rnd((M, N), dtype, gpu, seed=4)
+	gamma = torch.rand(N, generator=torch.Generator().manual_seed(5)) + 0.5
+	y2 = ops.linear_fwd(x, w, bias.to(gpu), residual=res, gamma=gamma.to(gpu), drop=((0.0, 0), d1, d2)[1:])
+	assert relerr(y2, rr + gamma.double() * (pre_ref * m12)) < TOL[dtype]
+	y3 = ops.linear_fwd(x, w, bias.to(gpu), residual=res, drop=((0.0, 0), d2))  # an inactive first entry is skipped
+	assert relerr(y3, rr + pre_ref * O.dropout_multiplier(d2[1], d2[0], M * N).reshape(M, N)) < TOL[dtype]
+	dy, dyr = rnd((M, K), dtype, gpu, seed=6)
+	w2, w2r = rnd((K, N), dtype, gpu, 0.1, seed=7)
+	du = ops.linear_dgrad(dy, w2, act=L.ACT_CODES["gelu"], pre=pre, drop=(d1,))
+	assert relerr(du, (dyr @ w2r) * m1 * O.act_grad(pre.cpu().double(), "gelu")) < TOL[dtype]
+	with pytest.raises(Exception):
+		ops.gemm(x, w, torch.empty((M, N), dtype=dtype, device=gpu), M, N, K, K, K, N, drop=(d1,))  # no epilogue to carry it
+
+
 @pytest.mark.parametrize("act", ["gelu", "silu"])
 def test_gemm_more_tiles_than_cus(gpu, act):
 	"""bf16 GEMMs with more 256x256 output tiles than the GPU has CUs (ragged last tile row and column): the

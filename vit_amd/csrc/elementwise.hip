@@ -46,19 +46,16 @@ struct ActB {
 	__device__ float operator()(float dy, float x, int64_t) const { return dy * act_deriv(x, act); }
 };
 
-// ---- dropout: keep(i) from splitmix64(seed + i) ---------------------------------------------------
+// ---- dropout: the shared counter-based mask (drop_keep in vitk_common.h) ---------------------------
 struct DropF {
-	float p, inv_keep;
-	uint64_t seed;
-	__device__ float operator()(float a, float, int64_t i) const {
-		uint64_t z = seed + (uint64_t)i * 0x9E3779B97F4A7C15ull;
-		z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-		z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-		z = z ^ (z >> 31);
-		const float u = (float)(z >> 40) * (1.0f / 16777216.0f);
-		return u >= p ? a * inv_keep : 0.f;
-	}
+	DropKey key;
+	float inv_keep;
+	__device__ float operator()(float a, float, int64_t i) const { return drop_keep(key, (uint64_t)i) ? a * inv_keep : 0.f; }
 };
+static inline DropF make_drop(float p, uint64_t seed) {
+	const DropKey k = make_drop_key(p, seed);
+	return DropF{k, drop_key_scale(k)};
+}
 
 // y = res + x * keep1(i) * keep2(i): one or two stacked dropouts and the residual add in one pass
 struct DropAddF {
@@ -469,14 +466,14 @@ extern "C" int vitk_act_bwd(const void* dy, const void* x, void* dx, int64_t n, 
 extern "C" int vitk_dropout(const void* x, void* y, int64_t n, float p, uint64_t seed, int dtype, void* stream) {
 	VITK_REQUIRE(x && y, VITK_ERR_NULL);
 	VITK_REQUIRE(n >= 0 && p >= 0.f && p < 1.f, VITK_ERR_SHAPE);
-	DISPATCH_T(dtype, return (launch_map2<T, T, T>(x, nullptr, y, n, DropF{p, 1.f / (1.f - p), seed}, (hipStream_t)stream)));
+	DISPATCH_T(dtype, return (launch_map2<T, T, T>(x, nullptr, y, n, make_drop(p, seed), (hipStream_t)stream)));
 }
 
 extern "C" int vitk_dropout_add(const void* x, const void* res, void* y, int64_t n, float p1, uint64_t seed1, float p2, uint64_t seed2, int dtype,
 	void* stream) {
 	VITK_REQUIRE(x && y, VITK_ERR_NULL);
 	VITK_REQUIRE(n >= 0 && p1 >= 0.f && p1 < 1.f && p2 >= 0.f && p2 < 1.f, VITK_ERR_SHAPE);
-	const DropAddF f{DropF{p1, 1.f / (1.f - p1), seed1}, DropF{p2, 1.f / (1.f - p2), seed2}, p2 > 0.f};
+	const DropAddF f{make_drop(p1, seed1), make_drop(p2, seed2), p2 > 0.f};
 	DISPATCH_T(dtype, return (launch_map2<T, T, T>(x, res, y, n, f, (hipStream_t)stream)));
 }
 

@@ -370,6 +370,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_256_kernel(BigArgs a) {
 				float v[4];
 #pragma unroll
 				for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] + bias4[j][r];
+				float keep[4] = {1.f, 1.f, 1.f, 1.f};  // fused dropout
+				if (EPI != VITK_EPI_NONE && g.drop[0].thr16) drop_keep_n<4>(g, m, nb, keep);
+				if (EPI == VITK_EPI_RESIDUAL || EPI == VITK_EPI_ACTGRAD) {
+#pragma unroll
+					for (int r = 0; r < 4; ++r) v[r] *= keep[r];
+				}
 				if (EPI == VITK_EPI_ACT) {
 					if (out2 != nullptr) {
 						// the pre-activation leaves straight from the accumulator layout (8 bytes per lane); the activation
@@ -391,7 +397,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_256_kernel(BigArgs a) {
 						}
 					}
 #pragma unroll
-					for (int r = 0; r < 4; ++r) v[r] = act_fwd<ACT>(v[r], g.act);
+					for (int r = 0; r < 4; ++r) v[r] = keep[r] * act_fwd<ACT>(v[r], g.act);
 				} else if (EPI == VITK_EPI_RESIDUAL || EPI == VITK_EPI_ACTGRAD) {
 					float x4[4] = {0.f, 0.f, 0.f, 0.f};
 					if (in) {
@@ -567,6 +573,7 @@ __device__ __forceinline__ void epilogue_wave_private(const BigArgs& a, const f3
 	// that leaves this quarter's requests and the previous quarter's stores in flight.  (Written as plain loads, the
 	// compiler sinks them to their uses and waits vmcnt(0) there, i.e. for every store issued before them.)  The
 	// "memory" clobbers pin the stores between the asm statements, which the count relies on.
+	const bool drop_on = g.drop[0].thr16 != 0;
 	u32x4 auxv[2][4];
 	const uint32_t aux_voff = (uint32_t)(r8 * (int)g.ld_aux + 8 * c8) * 2u;
 	if (HAS_AUX) {
@@ -598,6 +605,14 @@ __device__ __forceinline__ void epilogue_wave_private(const BigArgs& a, const f3
 			float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 #pragma unroll
 			for (int e = 0; e < 8; ++e) v[e] += er.bias8[e];
+			float keep[8];
+			if (EPI != VITK_EPI_NONE && drop_on) {  // fused dropout (wave-uniform branch)
+				drop_keep_n<8>(g, m, nb, keep);
+				if (EPI != VITK_EPI_ACT) {
+#pragma unroll
+					for (int e = 0; e < 8; ++e) v[e] *= keep[e];
+				}
+			}
 			if (EPI == VITK_EPI_ACT) {
 				if (out2 != nullptr) {
 					bf16x8 pre;
@@ -613,6 +628,10 @@ __device__ __forceinline__ void epilogue_wave_private(const BigArgs& a, const f3
 				} else {
 #pragma unroll
 					for (int e = 0; e < 8; ++e) v[e] = act_apply(v[e], g.act);
+				}
+				if (drop_on) {
+#pragma unroll
+					for (int e = 0; e < 8; ++e) v[e] *= keep[e];
 				}
 			} else if (EPI == VITK_EPI_RESIDUAL) {
 #pragma unroll

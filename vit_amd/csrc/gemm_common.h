@@ -21,6 +21,8 @@ struct GemmDev {
 	int64_t ld_aux;
 	void* out2;
 	int64_t ld_out2;
+	DropKey drop[2];   // fused dropout masks (thr16 == 0: off)
+	float drop_scale;  // product of the active masks' 1 / keep-probability
 };
 
 static inline GemmDev make_gemm_dev(const vitk_gemm_desc& d) {
@@ -35,6 +37,15 @@ static inline GemmDev make_gemm_dev(const vitk_gemm_desc& d) {
 	g.tpi = d.tokens_per_image;
 	g.bias = d.bias; g.gamma = d.gamma; g.pos = d.pos;
 	g.aux = d.aux; g.ld_aux = d.ld_aux; g.out2 = d.out2; g.ld_out2 = d.ld_out2;
+	g.drop_scale = 1.f;
+	int nd = 0;
+	for (int i = 0; i < 2; ++i) {
+		if (d.drop_p[i] > 0.f) {  // active masks are packed to the front: drop[0].thr16 == 0 means none
+			g.drop[nd] = make_drop_key(d.drop_p[i], d.drop_seed[i]);
+			g.drop_scale *= drop_key_scale(g.drop[nd]);
+			++nd;
+		}
+	}
 	return g;
 }
 
@@ -53,6 +64,31 @@ __device__ __forceinline__ int64_t patch_offset(const GemmDev& g, int64_t m, int
 
 __device__ __forceinline__ int64_t out_row(const GemmDev& g, int64_t m) { return g.tpi > 0 ? m + m / g.tpi + 1 : m; }
 
+// Fused dropout: multipliers (0 or g.drop_scale) of the N consecutive elements (m, n0 .. n0 + N - 1); the mask is
+// indexed by the logical element m * g.N + n.  Call only when g.drop[0].thr16 != 0.
+template <int N>
+__device__ __forceinline__ void drop_keep_n(const GemmDev& g, int64_t m, int64_t n0, float (&keep)[N]) {
+	const uint64_t i0 = (uint64_t)(m * g.N + n0);
+	if ((i0 & 1) == 0 && (N & 1) == 0) {  // aligned pairs: one hash per two elements and mask
+#pragma unroll
+		for (int j = 0; j < N / 2; ++j) {
+			const uint32_t b0 = drop_pair_bits(g.drop[0], (i0 >> 1) + j);
+			bool lo = (b0 & 0xffffu) >= g.drop[0].thr16, hi = (b0 >> 16) >= g.drop[0].thr16;
+			if (g.drop[1].thr16) {
+				const uint32_t b1 = drop_pair_bits(g.drop[1], (i0 >> 1) + j);
+				lo = lo && (b1 & 0xffffu) >= g.drop[1].thr16;
+				hi = hi && (b1 >> 16) >= g.drop[1].thr16;
+			}
+			keep[2 * j] = lo ? g.drop_scale : 0.f;
+			keep[2 * j + 1] = hi ? g.drop_scale : 0.f;
+		}
+	} else {
+#pragma unroll
+		for (int j = 0; j < N; ++j)
+			keep[j] = drop_keep(g.drop[0], i0 + j) && (!g.drop[1].thr16 || drop_keep(g.drop[1], i0 + j)) ? g.drop_scale : 0.f;
+	}
+}
+
 // Epilogue for ONE element.  EPI >= 0 fixes the epilogue kind at compile time (dead branches vanish), -1 reads g.epilogue.
 template <typename TIN, typename TOUT, int EPI = -1, int ACT = -1>
 __device__ __forceinline__ void epi_store1(const GemmDev& g, int64_t m, int64_t n, float acc) {
@@ -62,16 +98,22 @@ __device__ __forceinline__ void epi_store1(const GemmDev& g, int64_t m, int64_t 
 	if (g.bias) v += g.bias[n];
 	if (g.tpi > 0 && g.pos) v += g.pos[(1 + m % g.tpi) * g.N + n];
 	const int64_t r = out_row(g, m);
+	// fused dropout: multiplier of the masked quantity (the mask is indexed by the logical element m * N + n)
+	float keep = 1.f;
+	if (g.drop[0].thr16) {
+		const uint64_t i = (uint64_t)(m * g.N + n);
+		keep = drop_keep(g.drop[0], i) && (!g.drop[1].thr16 || drop_keep(g.drop[1], i)) ? g.drop_scale : 0.f;
+	}
 	if (epilogue == VITK_EPI_ACT) {
 		if (g.out2) reinterpret_cast<TOUT*>(g.out2)[r * g.ld_out2 + n] = from_f32<TOUT>(v);
 		// the activation sees the pre-activation as it is stored (rounded to the output type)
-		v = act_apply(g.out2 ? round_to<TOUT>(v) : v, act);
+		v = keep * act_apply(g.out2 ? round_to<TOUT>(v) : v, act);
 	} else if (epilogue == VITK_EPI_RESIDUAL) {
 		const float res = to_f32<TIN>(reinterpret_cast<const TIN*>(g.aux)[r * g.ld_aux + n]);
-		v = res + (g.gamma ? g.gamma[n] : 1.f) * v;
+		v = res + (g.gamma ? g.gamma[n] : 1.f) * (keep * v);
 	} else if (epilogue == VITK_EPI_ACTGRAD) {
 		const float u = to_f32<TIN>(reinterpret_cast<const TIN*>(g.aux)[r * g.ld_aux + n]);
-		v = v * act_deriv(u, act);
+		v = (keep * v) * act_deriv(u, act);
 	}
 	TOUT* c = reinterpret_cast<TOUT*>(g.C) + r * g.ldc + n;
 	if (g.accumulate) v += to_f32<TOUT>(*c);
@@ -97,6 +139,8 @@ __device__ __forceinline__ void epi_store4(const GemmDev& g, int64_t m, int64_t 
 		for (int j = 0; j < 4; ++j) v[j] += p[j];
 	}
 	const int64_t r = out_row(g, m);
+	float keep[4] = {1.f, 1.f, 1.f, 1.f};  // fused dropout (see epi_store1)
+	if (g.drop[0].thr16) drop_keep_n<4>(g, m, n0, keep);
 	if (epilogue == VITK_EPI_ACT) {
 		if (g.out2) {
 			store_vec<TOUT, 4>(reinterpret_cast<TOUT*>(g.out2) + r * g.ld_out2 + n0, v);
@@ -104,18 +148,18 @@ __device__ __forceinline__ void epi_store4(const GemmDev& g, int64_t m, int64_t 
 			for (int j = 0; j < 4; ++j) v[j] = round_to<TOUT>(v[j]);
 		}
 #pragma unroll
-		for (int j = 0; j < 4; ++j) v[j] = act_apply(v[j], act);
+		for (int j = 0; j < 4; ++j) v[j] = keep[j] * act_apply(v[j], act);
 	} else if (epilogue == VITK_EPI_RESIDUAL) {
 		float res[4], gm[4] = {1.f, 1.f, 1.f, 1.f};
 		load_vec<TIN, 4>(reinterpret_cast<const TIN*>(g.aux) + r * g.ld_aux + n0, res);
 		if (g.gamma) load_vec<float, 4>(g.gamma + n0, gm);
 #pragma unroll
-		for (int j = 0; j < 4; ++j) v[j] = res[j] + gm[j] * v[j];
+		for (int j = 0; j < 4; ++j) v[j] = res[j] + gm[j] * (keep[j] * v[j]);
 	} else if (epilogue == VITK_EPI_ACTGRAD) {
 		float u[4];
 		load_vec<TIN, 4>(reinterpret_cast<const TIN*>(g.aux) + r * g.ld_aux + n0, u);
 #pragma unroll
-		for (int j = 0; j < 4; ++j) v[j] *= act_deriv(u[j], act);
+		for (int j = 0; j < 4; ++j) v[j] = (keep[j] * v[j]) * act_deriv(u[j], act);
 	}
 	TOUT* c = reinterpret_cast<TOUT*>(g.C) + r * g.ldc + n0;
 	if (g.accumulate) {

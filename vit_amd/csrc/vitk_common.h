@@ -73,6 +73,60 @@ __device__ __forceinline__ float wave_max(float v) {
 	return v;
 }
 
+// ---- dropout masks --------------------------------------------------------------------------------
+// nn.Dropout (layers/vit.py:17-23, layers/transformers.py:20-21) as a counter-based mask: element i of a row-major
+// [M, N] tensor is kept iff 16 bits of a hash of (seed, i / 2) are >= p * 65536; elements 2j and 2j+1 share one hash.
+// The streaming dropout kernels and the GEMM epilogues evaluate the SAME function, so a mask applied by one in the
+// forward pass can be re-applied by the other in the backward pass from (p, seed) alone.  Kept values are scaled by
+// 65536 / (65536 - thr16), the exact inverse of the keep probability of the quantised threshold.
+struct DropKey {
+	uint32_t k0, k1;  // the seed, mixed on the host so that consecutive seeds give unrelated masks
+	uint32_t thr16;   // 0 = dropout off
+};
+__host__ __device__ __forceinline__ uint64_t vitk_splitmix64(uint64_t z) {
+	z += 0x9E3779B97F4A7C15ull;
+	z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+	z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+	return z ^ (z >> 31);
+}
+static inline DropKey make_drop_key(float p, uint64_t seed) {
+	DropKey k{0u, 0u, 0u};
+	if (p > 0.f) {
+		const uint64_t z = vitk_splitmix64(seed);
+		k.k0 = (uint32_t)z;
+		k.k1 = (uint32_t)(z >> 32);
+		const float t = p * 65536.0f + 0.5f;
+		k.thr16 = t >= 65535.f ? 65535u : (t < 1.f ? 1u : (uint32_t)t);
+	}
+	return k;
+}
+static inline float drop_key_scale(const DropKey& k) { return 65536.0f / (float)(65536u - k.thr16); }
+// 32 mask bits for elements 2 * pair and 2 * pair + 1 (low / high half)
+__host__ __device__ __forceinline__ uint32_t drop_pair_bits(const DropKey& k, uint64_t pair) {
+	uint32_t x = (uint32_t)pair ^ k.k0;
+	x ^= x >> 16;
+	x *= 0x7feb352du;
+	x += k.k1 + (uint32_t)(pair >> 32) * 0x9E3779B1u;
+	x ^= x >> 15;
+	x *= 0x846ca68bu;
+	x ^= x >> 16;
+	return x;
+}
+__host__ __device__ __forceinline__ bool drop_keep(const DropKey& k, uint64_t i) {
+	const uint32_t bits = drop_pair_bits(k, i >> 1);
+	return ((i & 1) ? (bits >> 16) : (bits & 0xffffu)) >= k.thr16;
+}
+// v[0..N) *= mask of elements i0 .. i0 + N - 1 (i0 even, N even); kept values are NOT scaled here
+template <int N>
+__device__ __forceinline__ void drop_mask_n(const DropKey& k, uint64_t i0, float (&v)[N]) {
+#pragma unroll
+	for (int j = 0; j < N / 2; ++j) {
+		const uint32_t bits = drop_pair_bits(k, (i0 >> 1) + j);
+		v[2 * j] = (bits & 0xffffu) >= k.thr16 ? v[2 * j] : 0.f;
+		v[2 * j + 1] = (bits >> 16) >= k.thr16 ? v[2 * j + 1] : 0.f;
+	}
+}
+
 // ---- activations (layers/transformers.py:26-33; F.gelu there is the exact erf form) -----------
 // Phi(u) = 0.5 * (1 + erf(u / sqrt 2)) through erfc(x) = poly(t) * exp(-x^2), t = 1 / (1 + p x), x = |u| / sqrt 2
 // (Abramowitz & Stegun 7.1.26, |error| <= 1.5e-7 absolute, evaluated on the erfc side so that the negative tail

@@ -198,8 +198,9 @@ def gemm_workspace(device):
 
 
 def gemm(A, B, C, M, N, K, lda, ldb, ldc, a_layout=L.K_MAJOR, b_layout=L.K_MAJOR, bias=None, epilogue=L.EPI_NONE, act=L.ACT_NONE,
-		aux=None, ld_aux=0, out2=None, ld_out2=0, gamma=None, accumulate=False, patch=None, tokens_per_image=0, pos=None, a_colsum=None, workspace=True):
-	"""C[M,N] (+)= epilogue(sum_k A(m,k) B(n,k)); see include/vitk.h for the operand layouts."""
+		aux=None, ld_aux=0, out2=None, ld_out2=0, gamma=None, accumulate=False, patch=None, tokens_per_image=0, pos=None, a_colsum=None, workspace=True, drop=()):
+	"""C[M,N] (+)= epilogue(sum_k A(m,k) B(n,k)); see include/vitk.h for the operand layouts.  drop: up to two (p, seed)
+	dropouts fused into the epilogue (entries with p == 0 are ignored)."""
 	L.require_gpu(A, B, C)
 	d = L.GemmDesc()
 	d.A, d.B, d.C = A.data_ptr(), B.data_ptr(), C.data_ptr()
@@ -216,6 +217,8 @@ def gemm(A, B, C, M, N, K, lda, ldb, ldc, a_layout=L.K_MAJOR, b_layout=L.K_MAJOR
 	d.aux, d.ld_aux = L.ptr(aux), ld_aux
 	d.out2, d.ld_out2 = L.ptr(out2), ld_out2
 	d.a_colsum = L.ptr(a_colsum)
+	for i, (p, seed) in enumerate([ds for ds in drop if ds[0] > 0.0]):
+		d.drop_p[i], d.drop_seed[i] = float(p), int(seed)
 	if workspace and a_layout == L.MN_MAJOR and C.dtype == torch.float32:  # weight gradients: the only form that splits K
 		ws = gemm_workspace(C.device)
 		d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
@@ -238,9 +241,10 @@ def gemm(A, B, C, M, N, K, lda, ldb, ldc, a_layout=L.K_MAJOR, b_layout=L.K_MAJOR
 	return C
 
 
-def linear_fwd(x, w, bias=None, act=L.ACT_NONE, residual=None, gamma=None, save_pre=False, out_dtype=None):
+def linear_fwd(x, w, bias=None, act=L.ACT_NONE, residual=None, gamma=None, save_pre=False, out_dtype=None, drop=()):
 	"""y = epilogue(x @ w.T + bias).  x: [M, K] (row stride may exceed K), w: [N, K] contiguous.
-	Returns y, or (y, pre_activation) with save_pre."""
+	Returns y, or (y, pre_activation) with save_pre.  drop: (p, seed) dropouts applied in the epilogue to the activation
+	output (act) or to the branch value before the residual add (residual)."""
 	M, K = x.shape
 	N = w.shape[0]
 	assert w.shape[1] == K and x.stride(1) == 1 and w.is_contiguous()
@@ -248,16 +252,18 @@ def linear_fwd(x, w, bias=None, act=L.ACT_NONE, residual=None, gamma=None, save_
 	pre = torch.empty_like(y) if save_pre else None
 	if residual is not None:
 		assert residual.shape == (M, N) and residual.stride(1) == 1
-		gemm(x, w, y, M, N, K, x.stride(0), K, N, bias=bias, epilogue=L.EPI_RESIDUAL, aux=residual, ld_aux=residual.stride(0), gamma=gamma)
+		gemm(x, w, y, M, N, K, x.stride(0), K, N, bias=bias, epilogue=L.EPI_RESIDUAL, aux=residual, ld_aux=residual.stride(0), gamma=gamma, drop=drop)
 	elif act != L.ACT_NONE:
-		gemm(x, w, y, M, N, K, x.stride(0), K, N, bias=bias, epilogue=L.EPI_ACT, act=act, out2=pre, ld_out2=N)
+		gemm(x, w, y, M, N, K, x.stride(0), K, N, bias=bias, epilogue=L.EPI_ACT, act=act, out2=pre, ld_out2=N, drop=drop)
 	else:
+		assert not any(ds[0] > 0.0 for ds in drop), "fused dropout needs an activation or residual epilogue"
 		gemm(x, w, y, M, N, K, x.stride(0), K, N, bias=bias)
 	return (y, pre) if save_pre else y
 
 
-def linear_dgrad(dy, w, act=L.ACT_NONE, pre=None, out=None):
-	"""dx = dy @ w, optionally multiplied by act'(pre) (pre = saved pre-activation of the layer that produced x)."""
+def linear_dgrad(dy, w, act=L.ACT_NONE, pre=None, out=None, drop=()):
+	"""dx = dy @ w, optionally multiplied by act'(pre) (pre = saved pre-activation of the layer that produced x) and, with
+	drop, by the mask of the dropout that followed the activation in the forward pass."""
 	M, N = dy.shape
 	K = w.shape[1]
 	assert w.shape[0] == N and dy.stride(1) == 1 and w.is_contiguous()
@@ -267,13 +273,13 @@ def linear_dgrad(dy, w, act=L.ACT_NONE, pre=None, out=None):
 		# operands K-major, the layout the large-tile GEMM runs fastest on
 		wt = weight_t(w)
 		if pre is not None:
-			gemm(dy, wt, dx, M, K, N, dy.stride(0), N, dx.stride(0), epilogue=L.EPI_ACTGRAD, act=act, aux=pre, ld_aux=pre.stride(0))
+			gemm(dy, wt, dx, M, K, N, dy.stride(0), N, dx.stride(0), epilogue=L.EPI_ACTGRAD, act=act, aux=pre, ld_aux=pre.stride(0), drop=drop)
 		else:
 			gemm(dy, wt, dx, M, K, N, dy.stride(0), N, dx.stride(0))
 		return dx
 	# sum over n: A = dy (n contiguous), B(n'=k, k'=n) = w[n, k] -> MN-major with ldb = K
 	if pre is not None:
-		gemm(dy, w, dx, M, K, N, dy.stride(0), K, dx.stride(0), b_layout=L.MN_MAJOR, epilogue=L.EPI_ACTGRAD, act=act, aux=pre, ld_aux=pre.stride(0))
+		gemm(dy, w, dx, M, K, N, dy.stride(0), K, dx.stride(0), b_layout=L.MN_MAJOR, epilogue=L.EPI_ACTGRAD, act=act, aux=pre, ld_aux=pre.stride(0), drop=drop)
 	else:
 		gemm(dy, w, dx, M, K, N, dy.stride(0), K, dx.stride(0), b_layout=L.MN_MAJOR)
 	return dx
@@ -473,18 +479,19 @@ class NormFn(torch.autograd.Function):
 		return dx, grad_as(dw, weight), grad_as(db, bias) if bias is not None else None, None, None, None
 
 
-def _ffn_forward(x2, w1, b1, w2, b2, act, gated, residual=None, gamma=None, drop1=(0.0, 0)):
+def _ffn_forward(x2, w1, b1, w2, b2, act, gated, residual=None, gamma=None, drop1=(0.0, 0), drop_out=()):
 	"""fc_in -> act / gate*act -> dropout1 -> fc_out (layers/transformers.py:45-57).  Returns (y, u, a) with `a` the
-	input of fc_out (after dropout1, which is applied in place)."""
+	input of fc_out (after dropout1: in the activation epilogue of fc_in, or in place after the gating kernel).
+	drop_out: dropouts on fc_out's result before the residual add, fused into its epilogue (needs `residual`)."""
 	if gated:
 		u = linear_fwd(x2, w1, b1)
 		F = w2.shape[1]
 		a = gated_act_fwd(u, F, act)
+		if drop1[0] > 0.0:
+			dropout_add(a, None, drop1[0], drop1[1], out=a)
 	else:
-		a, u = linear_fwd(x2, w1, b1, act=act, save_pre=True)
-	if drop1[0] > 0.0:
-		dropout_add(a, None, drop1[0], drop1[1], out=a)
-	y = linear_fwd(a, w2, b2, residual=residual, gamma=gamma)
+		a, u = linear_fwd(x2, w1, b1, act=act, save_pre=True, drop=(drop1,))
+	y = linear_fwd(a, w2, b2, residual=residual, gamma=gamma, drop=drop_out)
 	return y, u, a
 
 
@@ -498,9 +505,8 @@ def _ffn_backward(dy2, x2, u, a, w1, w2, act, gated, need_dx=True, outs=(None, N
 			dropout_add(da, None, drop1[0], drop1[1], out=da)
 		du = gated_act_bwd(da, u, w2.shape[1], act)
 	else:
-		du = linear_dgrad(dy2, w2, act=act, pre=u)
-		if drop1[0] > 0.0:  # the mask and the activation derivative are both elementwise factors
-			dropout_add(du, None, drop1[0], drop1[1], out=du)
+		# the dropout mask and the activation derivative are both elementwise factors of the same epilogue
+		du = linear_dgrad(dy2, w2, act=act, pre=u, drop=(drop1,))
 	dw1, db1 = linear_wgrad(du, x2, bias_grad=True, dw_out=outs[0], db_out=outs[1])
 	dx = linear_dgrad(du, w1) if need_dx else None
 	return dx, dw1, db1, dw2, db2
@@ -530,13 +536,15 @@ class FeedForwardFn(torch.autograd.Function):
 		return dx, grad_as(dw1, w1), grad_as(db1, b1), grad_as(dw2, w2), grad_as(db2, b2), None, None
 
 
-def _mha_forward(x2, wqkv, wo, bo, B, S, n_head, residual=None, gamma=None, drop=(0.0, 0)):
-	"""qkv projection -> attention -> out projection (layers/attention.py:27-48).  Returns (y, qkv, o, lse)."""
+def _mha_forward(x2, wqkv, wo, bo, B, S, n_head, residual=None, gamma=None, drop=(0.0, 0), drop_out=()):
+	"""qkv projection -> attention -> out projection (layers/attention.py:27-48).  Returns (y, qkv, o, lse).
+	drop: dropout on the attention probabilities; drop_out: dropouts on the projection's result before the residual
+	add, fused into its epilogue (needs `residual`)."""
 	d = x2.shape[1]
 	dh = d // n_head
 	qkv = linear_fwd(x2, wqkv)
 	o, lse = attention_fwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], B, n_head, S, S, dh, drop=drop)
-	y = linear_fwd(o, wo, bo, residual=residual, gamma=gamma)
+	y = linear_fwd(o, wo, bo, residual=residual, gamma=gamma, drop=drop_out)
 	return y, qkv, o, lse
 
 
@@ -600,24 +608,15 @@ class ViTBlockFn(torch.autograd.Function):
 		x0 = _flat(cast(x, dt))
 		wqkv_c, wo_c, w1_c, w2_c = (weight_as(t, dt) for t in (wqkv, wo, w1, w2))
 		n1, _, mean1, rstd1 = norm_fwd(x0, f32(n1w), f32(n1b), kind, eps, unit_offset)
-		if ls1 is None and d_a[0] == 0.0:
-			x1, qkv, o, lse = _mha_forward(n1, wqkv_c, wo_c, f32(bo), B, S, n_head, residual=x0, drop=d_attn)
-			br1 = None
-		elif ls1 is None:
-			x1, qkv, o, lse = _mha_forward(n1, wqkv_c, wo_c, f32(bo), B, S, n_head, drop=d_attn)
-			dropout_add(x1, x0, d_a[0], d_a[1], out=x1)  # x0 + dropout(branch), in the branch's buffer
+		if ls1 is None:  # residual add (and the branch dropout, if any) in the projection's epilogue
+			x1, qkv, o, lse = _mha_forward(n1, wqkv_c, wo_c, f32(bo), B, S, n_head, residual=x0, drop=d_attn, drop_out=(d_a,))
 			br1 = None
 		else:
 			br1, qkv, o, lse = _mha_forward(n1, wqkv_c, wo_c, f32(bo), B, S, n_head)
 			x1 = scale_residual(br1, x0, f32(ls1))
 		n2, _, mean2, rstd2 = norm_fwd(x1, f32(n2w), f32(n2b), kind, eps, unit_offset)
-		if ls2 is None and d_f2[0] == 0.0 and d_b[0] == 0.0:
-			x2, u, a = _ffn_forward(n2, w1_c, f32(b1), w2_c, f32(b2), act, gated, residual=x1, drop1=d_f1)
-			br2 = None
-		elif ls2 is None:
-			x2, u, a = _ffn_forward(n2, w1_c, f32(b1), w2_c, f32(b2), act, gated, drop1=d_f1)
-			m1, m2 = (d_f2, d_b) if d_f2[0] > 0.0 else (d_b, off)
-			dropout_add(x2, x1, m1[0], m1[1], m2[0], m2[1], out=x2)
+		if ls2 is None:
+			x2, u, a = _ffn_forward(n2, w1_c, f32(b1), w2_c, f32(b2), act, gated, residual=x1, drop1=d_f1, drop_out=(d_f2, d_b))
 			br2 = None
 		else:
 			br2, u, a = _ffn_forward(n2, w1_c, f32(b1), w2_c, f32(b2), act, gated)
