@@ -185,24 +185,27 @@ __global__ __launch_bounds__(1024) void attn_fwd_mfma_kernel(AttnArgs a) {
 				l += p;
 			}
 		l = group_sum(l);
-		if constexpr (DROP) {
-			// the normaliser l is that of the full softmax; dropped probabilities leave the P V product only
-			const uint32_t rk = attn_row_key(attn_head_key(a, bh), q);
-#pragma unroll
-			for (int t = 0; t < 2 * KT2; ++t) {
-				const int k0 = 16 * t + 4 * g;
-				const uint32_t b0 = attn_pair_bits(rk, k0 >> 1), b1 = attn_pair_bits(rk, (k0 >> 1) + 1);
-				st[t][0] *= attn_keep(b0, 0, a.drop_thr16, 1.f);
-				st[t][1] *= attn_keep(b0, 1, a.drop_thr16, 1.f);
-				st[t][2] *= attn_keep(b1, 0, a.drop_thr16, 1.f);
-				st[t][3] *= attn_keep(b1, 1, a.drop_thr16, 1.f);
-			}
-		}
+		// dropout: the normaliser l is that of the full softmax; dropped probabilities leave the P V product only.  The
+		// mask of a key tile is drawn right before that tile is packed (drawn for all tiles up front, the hash
+		// temporaries of 28 unrolled draws spill)
+		uint32_t rk = 0;
+		if constexpr (DROP) rk = attn_row_key(attn_head_key(a, bh), q);
 		f32x4 o[4];
 #pragma unroll
 		for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
 		for (int u = 0; u < KT2; ++u) {
+			if constexpr (DROP) {
+#pragma unroll
+				for (int t = 2 * u; t < 2 * u + 2; ++t) {
+					const int k0 = 16 * t + 4 * g;
+					const uint32_t b0 = attn_pair_bits(rk, k0 >> 1), b1 = attn_pair_bits(rk, (k0 >> 1) + 1);
+					st[t][0] *= attn_keep(b0, 0, a.drop_thr16, 1.f);
+					st[t][1] *= attn_keep(b0, 1, a.drop_thr16, 1.f);
+					st[t][2] *= attn_keep(b1, 0, a.drop_thr16, 1.f);
+					st[t][3] *= attn_keep(b1, 1, a.drop_thr16, 1.f);
+				}
+			}
 			const bf16x8 pf = pack8(st[2 * u], st[2 * u + 1]);
 #pragma unroll
 			for (int dt = 0; dt < 4; ++dt) o[dt] = mfma16(tr_frag(Vs, 32 * u, 32 * u + 16, 16 * dt, lane), pf, o[dt]);
