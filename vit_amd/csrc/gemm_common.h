@@ -69,13 +69,17 @@ __device__ __forceinline__ int64_t out_row(const GemmDev& g, int64_t m) { return
 template <int N>
 __device__ __forceinline__ void drop_keep_n(const GemmDev& g, int64_t m, int64_t n0, float (&keep)[N]) {
 	const uint64_t i0 = (uint64_t)(m * g.N + n0);
-	if ((i0 & 1) == 0 && (N & 1) == 0) {  // aligned pairs: one hash per two elements and mask
+	if ((N & (N - 1)) == 0 && N >= 2 && (i0 & (N - 1)) == 0) {
+		// an aligned group of N: one hash per two elements and mask, and pair + j cannot carry into the upper index word
+		const uint64_t pair0 = i0 >> 1;
+		const uint32_t p0 = (uint32_t)pair0;
+		const uint32_t h0 = drop_hi_term(g.drop[0], pair0), h1 = drop_hi_term(g.drop[1], pair0);
 #pragma unroll
 		for (int j = 0; j < N / 2; ++j) {
-			const uint32_t b0 = drop_pair_bits(g.drop[0], (i0 >> 1) + j);
+			const uint32_t b0 = drop_pair_bits_lo(g.drop[0], h0, p0 + j);
 			bool lo = (b0 & 0xffffu) >= g.drop[0].thr16, hi = (b0 >> 16) >= g.drop[0].thr16;
 			if (g.drop[1].thr16) {
-				const uint32_t b1 = drop_pair_bits(g.drop[1], (i0 >> 1) + j);
+				const uint32_t b1 = drop_pair_bits_lo(g.drop[1], h1, p0 + j);
 				lo = lo && (b1 & 0xffffu) >= g.drop[1].thr16;
 				hi = hi && (b1 >> 16) >= g.drop[1].thr16;
 			}

@@ -102,15 +102,20 @@ static inline DropKey make_drop_key(float p, uint64_t seed) {
 }
 static inline float drop_key_scale(const DropKey& k) { return 65536.0f / (float)(65536u - k.thr16); }
 // 32 mask bits for elements 2 * pair and 2 * pair + 1 (low / high half)
-__host__ __device__ __forceinline__ uint32_t drop_pair_bits(const DropKey& k, uint64_t pair) {
-	uint32_t x = (uint32_t)pair ^ k.k0;
+// split in two so that callers walking consecutive pairs whose upper index word cannot change hoist the first part
+__host__ __device__ __forceinline__ uint32_t drop_hi_term(const DropKey& k, uint64_t pair) { return k.k1 + (uint32_t)(pair >> 32) * 0x9E3779B1u; }
+__host__ __device__ __forceinline__ uint32_t drop_pair_bits_lo(const DropKey& k, uint32_t hi_term, uint32_t pair_lo) {
+	uint32_t x = pair_lo ^ k.k0;
 	x ^= x >> 16;
 	x *= 0x7feb352du;
-	x += k.k1 + (uint32_t)(pair >> 32) * 0x9E3779B1u;
+	x += hi_term;
 	x ^= x >> 15;
 	x *= 0x846ca68bu;
 	x ^= x >> 16;
 	return x;
+}
+__host__ __device__ __forceinline__ uint32_t drop_pair_bits(const DropKey& k, uint64_t pair) {
+	return drop_pair_bits_lo(k, drop_hi_term(k, pair), (uint32_t)pair);
 }
 __host__ __device__ __forceinline__ bool drop_keep(const DropKey& k, uint64_t i) {
 	const uint32_t bits = drop_pair_bits(k, i >> 1);
