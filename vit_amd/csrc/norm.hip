@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256) void norm_fwd_kernel(const T* __restrict__ x, 
 	}
 }
 
-constexpr int BWD_THREADS = 256;  // 4 waves; at most 3 workgroups per CU are launched (register budget), so few workgroups add into dgamma / dbeta
+constexpr int BWD_THREADS = 768;  // 12 waves = 3 per SIMD (170 registers each), ONE workgroup per CU: every workgroup ends with a float atomic per column into dgamma / dbeta, and atomics from different XCDs on one address serialise at the memory side (768 workgroups spent 30 of 77 us there)
 
 template <typename T, int VEC, int ITERS, bool RMS>
 __global__ __launch_bounds__(BWD_THREADS) void norm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
@@ -119,38 +119,43 @@ __global__ __launch_bounds__(BWD_THREADS) void norm_bwd_kernel(const T* __restri
 			}
 		}
 	}
-	// The next row's operands are requested (as packed 16-byte registers) before this row is worked on: a wave keeps
-	// two rows of loads in flight, which is what it takes to cover the HBM latency at 4 waves per SIMD.
-	Pack<T, VEC> px[ITERS], pdy[ITERS], pres[ITERS];
-	float pmu = 0.f, prs = 0.f;
-	auto fetch = [&](int64_t row) {
-		if (!RMS) pmu = mean[row];
-		prs = rstd_in[row];
+	// The operands of the next TWO rows of this wave are in flight (as packed registers) while a row is worked on: the
+	// kernel is bound by memory-level parallelism (bytes in flight = bandwidth x latency), not by issue or arithmetic;
+	// with one row ahead the 12 waves of a CU keep about 14 MB in flight chip-wide, half of what 8 TB/s needs.
+	struct Pre {
+		Pack<T, VEC> x[ITERS], dy[ITERS], res[ITERS];
+		float mu, rs;
+	};
+	Pre pa, pb;
+	pa.mu = pa.rs = pb.mu = pb.rs = 0.f;
+	auto fetch = [&](Pre& p, int64_t row) {
+		if (row >= rows) return;
+		if (!RMS) p.mu = mean[row];
+		p.rs = rstd_in[row];
 #pragma unroll
 		for (int it = 0; it < ITERS; ++it) {
 			const int c = lane + it * 64;
 			if (c < nchunk) {
-				px[it] = *reinterpret_cast<const Pack<T, VEC>*>(x + row * d + c * VEC);
-				pdy[it] = *reinterpret_cast<const Pack<T, VEC>*>(dy + row * d + c * VEC);
-				if (dres != nullptr) pres[it] = *reinterpret_cast<const Pack<T, VEC>*>(dres + row * d + c * VEC);
+				p.x[it] = *reinterpret_cast<const Pack<T, VEC>*>(x + row * d + c * VEC);
+				p.dy[it] = *reinterpret_cast<const Pack<T, VEC>*>(dy + row * d + c * VEC);
+				if (dres != nullptr) p.res[it] = *reinterpret_cast<const Pack<T, VEC>*>(dres + row * d + c * VEC);
 			}
 		}
 	};
-	const int64_t row0 = (int64_t)blockIdx.x * WAVES + wave;
-	if (row0 < rows) fetch(row0);
-	for (int64_t row = row0; row < rows; row += nwaves) {
-		const float mu = pmu, rs = prs;
+	// works on row `row`, whose operands are in p, and refills p with row `next`
+	auto work = [&](Pre& p, int64_t row, int64_t next) {
+		const float mu = p.mu, rs = p.rs;
 		float xh[ITERS][VEC], g[ITERS][VEC], rres[ITERS][VEC], dyv[ITERS][VEC];
 #pragma unroll
 		for (int it = 0; it < ITERS; ++it) {
 #pragma unroll
 			for (int j = 0; j < VEC; ++j) {
-				xh[it][j] = to_f32<T>(px[it].v[j]);
-				dyv[it][j] = to_f32<T>(pdy[it].v[j]);
-				rres[it][j] = dres != nullptr ? to_f32<T>(pres[it].v[j]) : 0.f;
+				xh[it][j] = to_f32<T>(p.x[it].v[j]);
+				dyv[it][j] = to_f32<T>(p.dy[it].v[j]);
+				rres[it][j] = dres != nullptr ? to_f32<T>(p.res[it].v[j]) : 0.f;
 			}
 		}
-		if (row + nwaves < rows) fetch(row + nwaves);
+		fetch(p, next);
 		float s1 = 0.f, s2 = 0.f;
 #pragma unroll
 		for (int it = 0; it < ITERS; ++it) {
@@ -189,6 +194,13 @@ __global__ __launch_bounds__(BWD_THREADS) void norm_bwd_kernel(const T* __restri
 				store_vec<T, VEC>(dx + row * d + c * VEC, o);
 			}
 		}
+	};
+	const int64_t row0 = (int64_t)blockIdx.x * WAVES + wave;
+	fetch(pa, row0);
+	fetch(pb, row0 + nwaves);
+	for (int64_t row = row0; row < rows; row += 2 * nwaves) {
+		work(pa, row, row + 2 * nwaves);
+		if (row + nwaves < rows) work(pb, row + nwaves, row + 3 * nwaves);
 	}
 	// column sums: waves of the block combine in LDS, then one float atomic per column per block
 #pragma unroll
@@ -233,7 +245,7 @@ int launch_fwd(const NormArgs& a, hipStream_t st) {
 }
 template <typename T, int VEC, int ITERS, bool RMS>
 int launch_bwd(const NormArgs& a, hipStream_t st) {
-	int grid = (int)std::min<int64_t>(vitk_cdiv(a.rows, BWD_THREADS / 64), 768);
+	int grid = (int)std::min<int64_t>(vitk_cdiv(a.rows, BWD_THREADS / 64), 256);
 	size_t lds = (size_t)2 * a.d * sizeof(float);
 	hipLaunchKernelGGL((norm_bwd_kernel<T, VEC, ITERS, RMS>), dim3(grid), dim3(BWD_THREADS), lds, st, (const T*)a.dy, (const T*)a.x, a.gamma, a.mean_in,
 		a.rstd_in, (const T*)a.dres, (T*)a.dx, a.dgamma, a.dbeta, a.rows, a.d, a.offset);
