@@ -128,7 +128,8 @@ int64_t vitk_gemm_workspace_bytes(void);
 int vitk_gemm_uses_bf16_mfma(const vitk_gemm_desc* desc);
 
 /* ------------------------------------------------------------------------------------------
- * Row normalisation.  rows = B*N tokens, d = d_model.
+ * Row normalisation.  rows = B*N tokens, d = d_model <= 4096 when d and the pointers allow 16-byte accesses
+ * (d % 4 == 0 in float32, d % 8 == 0 in bfloat16), else d <= 1024; beyond that VITK_ERR_UNSUPPORTED.
  * LayerNorm: nn.LayerNorm injected through config.norm (layers/vit.py:15,20,38,49; eps 1e-5).
  * RMSNorm: layers/norm.py:19-31 (fp32 internal, y = x * rsqrt(mean(x^2)+eps) * (unit_offset + w)).
  * If `res` is non-null the kernel first forms s = x + res, writes s to `sum_out` (the new

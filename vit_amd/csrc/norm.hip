@@ -275,19 +275,22 @@ int dispatch(const NormArgs& a, bool vec_ok, hipStream_t st) {
 		if (iters <= 2) NORM_GO(V, 2);
 		if (iters <= 4) NORM_GO(V, 4);
 		if (iters <= 8) NORM_GO(V, 8);
-		return VITK_ERR_SHAPE;
+		if (iters <= 16) NORM_GO(V, 16);
+		return VITK_ERR_UNSUPPORTED;
 	}
+	// rows that cannot be read in 16-byte pieces (d or a pointer unaligned): one element per lane and step, d <= 1024
 	const int iters = (int)vitk_cdiv(a.d, 64);
 	if (iters <= 1) NORM_GO(1, 1);
 	if (iters <= 4) NORM_GO(1, 4);
 	if (iters <= 16) NORM_GO(1, 16);
-	return VITK_ERR_SHAPE;
+	return VITK_ERR_UNSUPPORTED;
 #undef NORM_GO
 }
 
 template <bool RMS, bool FWD>
 int run(const NormArgs& a, int dtype, hipStream_t st) {
-	VITK_REQUIRE(a.rows > 0 && a.d > 0 && a.d <= 8192, VITK_ERR_SHAPE);
+	VITK_REQUIRE(a.rows > 0 && a.d > 0, VITK_ERR_SHAPE);
+	VITK_REQUIRE(a.d <= 4096, VITK_ERR_UNSUPPORTED);  // the row lives in registers
 	bool vec_ok = vitk_aligned(a.x, 16) && vitk_aligned(a.gamma, 16) && (a.beta == nullptr || vitk_aligned(a.beta, 16)) &&
 		(a.res == nullptr || vitk_aligned(a.res, 16)) && (a.y == nullptr || vitk_aligned(a.y, 16)) && (a.sum_out == nullptr || vitk_aligned(a.sum_out, 16)) &&
 		(a.dy == nullptr || vitk_aligned(a.dy, 16)) && (a.dres == nullptr || vitk_aligned(a.dres, 16)) && (a.dx == nullptr || vitk_aligned(a.dx, 16));
