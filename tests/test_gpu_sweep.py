@@ -137,3 +137,122 @@ def test_norm_random_shapes(gpu, dtype, kind):
 			dx_ref, dw_ref = O.rmsnorm_bwd(dyr, xs, w.double(), r_ref, True)
 		assert relerr(dx, dx_ref) < TOL[dtype], (rows, d)
 		assert relerr(dw, dw_ref) < 1e-4, (rows, d)
+
+
+@pytest.mark.parametrize("case", range(6 * SCALE))
+def test_vit_random_configs(gpu, case):
+	"""Whole ViT forward + cross entropy + backward for random configurations (width, heads, depth, patch grid,
+	feed-forward width, norm, activation incl. gated ones, LayerScale) against the oracle's forward and its autograd
+	gradients: float32 at 1e-4 / 2e-4, bf16 autocast at 2e-2 / 4e-2."""
+	import torch.nn as nn
+	from vit_amd import ops
+	from vit_amd.layers import MHA, RMSNorm
+	from vit_amd.models import ViT
+	r = random.Random(900 + case)
+	dh = r.choice([64, 64, 32, 24, 12])
+	heads = r.randint(1, 4)
+	norm = r.choice(["layernorm", "rmsnorm"])
+	act = r.choice(["gelu", "silu", "relu", "relu6", "swiglu", "geglu", "reglu"])
+	n_patch = r.choice([2, 4, 7, 8])
+	px = r.choice([2, 4])
+	B = r.randint(1, 9)
+
+	class Cfg:
+		attention = MHA
+		use_qk_norm = False
+		dropout = 0.0
+	Cfg.norm = nn.LayerNorm if norm == "layernorm" else RMSNorm
+	Cfg.activation = act
+	Cfg.use_layer_scale = r.random() < 0.3
+	Cfg.d_model = heads * dh
+	Cfg.n_head = heads
+	Cfg.n_block = r.randint(1, 3)
+	Cfg.n_patch = n_patch
+	Cfg.d_ff = r.choice([Cfg.d_model * 2, Cfg.d_model * 4, 8 * r.randint(3, 40)])
+	Cfg.out_d = r.choice([10, 7, 100])
+	Cfg.chw = (3, n_patch * px, n_patch * px)
+	torch.manual_seed(case)
+	model = ViT(Cfg())
+	if Cfg.use_layer_scale:  # the 1e-4 initial value would hide the branches: make them count
+		with torch.no_grad():
+			for n, p in model.named_parameters():
+				if "layer_scale" in n:
+					p.fill_(0.5)
+	sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+	x = torch.randn(B, *Cfg.chw)
+	y = torch.randint(0, Cfg.out_d, (B,))
+	fwd = lambda im, s: O.vit_fwd(im, s, n_patch, Cfg.n_block, heads, norm, act)
+	ref_logits, ref_loss, ref_grads, _ = O.loss_and_grads(fwd, sd, x, y)
+	model = model.to(gpu)
+	tag = dict(d=Cfg.d_model, h=heads, L=Cfg.n_block, P=n_patch, px=px, ff=Cfg.d_ff, norm=norm, act=act, ls=Cfg.use_layer_scale, B=B)
+	for dtype, tol in ((torch.float32, 1e-4), (torch.bfloat16, 2e-2)):
+		model.zero_grad()
+		with torch.autocast("cuda", dtype=torch.bfloat16, enabled=(dtype == torch.bfloat16)):
+			logits = model(x.to(gpu))
+			logits = logits[0] if isinstance(logits, tuple) else logits
+			loss = ops.cross_entropy(logits, y.to(gpu))
+		loss.backward()
+		assert relerr(logits, ref_logits) < tol, (tag, dtype)
+		relu_like = act in ("relu", "relu6", "reglu")
+		for k, p in model.named_parameters():
+			# bf16 gradients through a ReLU kink differ where a pre-activation rounds across zero: L2 measure there
+			g, want = p.grad.float().cpu().double(), ref_grads[k].double()
+			if dtype == torch.bfloat16 and relu_like:
+				e = float((g - want).norm() / want.norm().clamp_min(1e-30))
+				assert e < 0.25, (tag, k, e)
+			else:
+				assert relerr(g, want) < 2 * tol, (tag, k, dtype)
+
+
+@pytest.mark.parametrize("case", range(4 * SCALE))
+def test_cvt_random_configs(gpu, case):
+	"""Whole CvT (conv embeddings with BatchNorm in training mode, conv-projection attention with strided keys, three
+	stages) for random widths / heads / depths / image sizes against the oracle's forward and its autograd gradients;
+	the bars are those of the golden CvT test (float32 2e-4 / 1e-3, bf16 3e-2 / 8e-2)."""
+	import torch.nn as nn
+	from vit_amd import ops
+	from vit_amd.layers import RMSNorm
+	from vit_amd.models import CvT
+	r = random.Random(4000 + case)
+	norm = r.choice(["layernorm", "rmsnorm"])
+	act = r.choice(["gelu", "silu", "swiglu"])
+	c = {"chw": (3, *(2 * (r.choice([32, 48, 64]),))), "out_d": r.choice([10, 37]), "norm": norm, "activation": act,
+		"use_layer_scale": r.random() < 0.3}
+	for s, (ek, es, ep) in zip((1, 2, 3), ((7, 4, 2), (3, 2, 1), (3, 2, 1))):
+		heads = r.randint(1, 3)
+		c[f"s{s}_heads"] = heads
+		c[f"s{s}_emb_dim"] = heads * r.choice([32, 64])
+		c[f"s{s}_depth"] = r.randint(1, 2)
+		c[f"s{s}_mlp_ratio"] = r.choice([1.0, 2.0, 4.0])
+		c[f"s{s}_emb_kernel"], c[f"s{s}_emb_stride"], c[f"s{s}_emb_pad"] = ek, es, ep
+		c[f"s{s}_qkv_kernel"], c[f"s{s}_qkv_stride"], c[f"s{s}_qkv_pad"] = 3, (1 if s == 1 else 2), 1
+	B = r.randint(2, 6)
+
+	class Cfg:
+		dropout = 0.0
+	for k, v in c.items():
+		setattr(Cfg, k, v)
+	Cfg.norm = nn.LayerNorm if norm == "layernorm" else RMSNorm
+	torch.manual_seed(case)
+	model = CvT(Cfg())
+	with torch.no_grad():
+		for n, p in model.named_parameters():
+			if "layer_scale" in n:
+				p.fill_(0.5)
+	sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+	x = torch.randn(B, *c["chw"])
+	y = torch.randint(0, c["out_d"], (B,))
+	ref_logits, ref_loss, ref_grads, ref_dx = O.loss_and_grads(lambda im, s: O.cvt_fwd(im, s, c, True), sd, x, y)
+	model = model.to(gpu).train()
+	for dtype, tol, gtol in ((torch.float32, 2e-4, 1e-3), (torch.bfloat16, 3e-2, 8e-2)):
+		model.load_state_dict(sd)  # BatchNorm running statistics move with every training forward
+		model.zero_grad()
+		xi = x.to(gpu).requires_grad_(True)
+		with torch.autocast("cuda", dtype=torch.bfloat16, enabled=(dtype == torch.bfloat16)):
+			logits = model(xi)
+			loss = ops.cross_entropy(logits.float(), y.to(gpu))
+		loss.backward()
+		assert relerr(logits, ref_logits) < tol, (c, dtype)
+		assert relerr(xi.grad, ref_dx) < gtol, (c, dtype)
+		for k, p in model.named_parameters():
+			assert relerr(p.grad, ref_grads[k]) < gtol, (c, k, dtype)
