@@ -256,3 +256,50 @@ def test_cvt_random_configs(gpu, case):
 		assert relerr(xi.grad, ref_dx) < gtol, (c, dtype)
 		for k, p in model.named_parameters():
 			assert relerr(p.grad, ref_grads[k]) < gtol, (c, k, dtype)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", range(4 * SCALE))
+def test_fused_block_dropout_random_configs(gpu, dtype, case):
+	"""The fused ViTBlock with the reference's dropout (attention probabilities, both branches, both feed-forward
+	dropouts: masks drawn inside the attention kernels and the GEMM epilogues) against the module-by-module composition
+	(streaming dropout kernels) under the same seeds, for random widths, token counts and feed-forward widths."""
+	import torch.nn as nn
+	from vit_amd import ops
+	from vit_amd.layers import MHA, RMSNorm, ViTBlock
+	r = random.Random(7000 + case)
+	heads = r.randint(1, 4)
+	dh = r.choice([64, 32, 24])
+
+	class Cfg:
+		use_layer_scale = False
+		use_qk_norm = False
+		attention = MHA
+	Cfg.d_model = heads * dh
+	Cfg.n_head = heads
+	Cfg.d_ff = 8 * r.randint(4, 64)
+	Cfg.dropout = r.choice([0.1, 0.3, 0.5])
+	Cfg.activation = r.choice(["gelu", "silu", "swiglu", "geglu"])
+	Cfg.norm = r.choice([nn.LayerNorm, RMSNorm])
+	B, S = r.randint(1, 6), r.randint(2, 200)
+	torch.manual_seed(case)
+	blk = ViTBlock(Cfg()).to(gpu).train()
+	x = torch.randn(B, S, Cfg.d_model, device=gpu).to(dtype)
+	gy = torch.randn(B, S, Cfg.d_model, device=gpu).to(dtype)
+	results = []
+	for fused in (True, False):
+		if not fused:
+			blk._fusable = lambda: False
+		torch.manual_seed(11)
+		ops._dropout_calls[0] = 0
+		xi = x.clone().requires_grad_()
+		blk.zero_grad()
+		y, _ = blk(xi)
+		y.backward(gy)
+		results.append((y.detach(), xi.grad, {k: p.grad.clone() for k, p in blk.named_parameters()}))
+	(y1, dx1, g1), (y2, dx2, g2) = results
+	tag = (Cfg.d_model, heads, Cfg.d_ff, Cfg.dropout, Cfg.activation, Cfg.norm.__name__, B, S)
+	tol = 1e-5 if dtype == torch.float32 else 2e-2
+	assert relerr(y1, y2) < tol and relerr(dx1, dx2) < 2 * tol, tag
+	for k in g1:
+		assert relerr(g1[k], g2[k]) < (1e-4 if dtype == torch.float32 else 4e-2), (tag, k)
