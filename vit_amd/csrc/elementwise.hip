@@ -1,6 +1,7 @@
 // Bandwidth-bound elementwise, gather and reduction kernels of the ViT/CvT hot path.
 // All of them stream 16 bytes per lane when pointers and extents allow, else fall back to
 // one element per lane.
+#include <cstdlib>
 #include "vitk_common.h"
 
 namespace {
@@ -119,9 +120,12 @@ int launch_colsum(const void* x, float* out, int64_t M, int64_t N, int64_t ld, h
 	const int vw = vec ? V : 1;
 	const int64_t chunks = vitk_cdiv(N, vw);
 	const int cx = (int)std::min<int64_t>(128, vitk_cdiv(chunks, 32) * 32);  // lanes along columns
-	const int ry = std::max(1, 1024 / cx);
+	static const int tpb = std::getenv("VITK_COLSUM_TPB") ? atoi(std::getenv("VITK_COLSUM_TPB")) : 1024;
+	static const int gymax = std::getenv("VITK_COLSUM_GY") ? atoi(std::getenv("VITK_COLSUM_GY")) : 128;
+	static const int rpt = std::getenv("VITK_COLSUM_RPT") ? atoi(std::getenv("VITK_COLSUM_RPT")) : 4;
+	const int ry = std::max(1, tpb / cx);
 	const unsigned gx = (unsigned)vitk_cdiv(chunks, cx);
-	const unsigned gy = (unsigned)std::max<int64_t>(1, std::min<int64_t>(vitk_cdiv(M, (int64_t)ry * 4), 128));
+	const unsigned gy = (unsigned)std::max<int64_t>(1, std::min<int64_t>(vitk_cdiv(M, (int64_t)ry * rpt), gymax));
 	const size_t lds = (size_t)ry * cx * vw * sizeof(float);
 	if (vec)
 		hipLaunchKernelGGL((colsum_kernel<T, V>), dim3(gx, gy), dim3(cx, ry), lds, st, (const T*)x, out, M, N, ld);

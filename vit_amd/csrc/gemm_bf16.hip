@@ -122,6 +122,9 @@ struct BfArgs {
 	int tiles_m, tiles_n, splits, k_per_split;  // k_per_split is a multiple of BK
 	int vec4;                                    // epilogue may use 4-wide accesses
 	int dma;                                     // K-major x K-major, K % 64 == 0: operand tiles by LDS-DMA
+	float* partials;                             // K split through scratch: [split][tile][128 x 128] partial tiles (else float atomics into C)
+	float* cs_partials;                          // [split][M] partial column sums of A (with partials and a_colsum)
+	float* a_colsum;                             // MN-major A: a_colsum[m] += sum_k A(m, k), formed from the staged A tiles
 };
 
 typedef __attribute__((address_space(3))) void* lds_void_p;
@@ -208,6 +211,27 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(BfArgs a) {
 		}
 	};
 
+	// Column sums of an MN-major A (the bias gradient next to a weight gradient): a thread stages 8 fixed columns of
+	// 4 k rows per K tile through its registers anyway, so it adds them up on the way; the workgroups of the first tile
+	// column do it (all tile columns stage the same A).  Out-of-range pieces were read as zeros.
+	bool do_colsum = false;
+	if constexpr (ALAYOUT == VITK_MN_MAJOR) do_colsum = a.a_colsum != nullptr && tn == 0;
+	float csum[8];
+#pragma unroll
+	for (int e = 0; e < 8; ++e) csum[e] = 0.f;
+	auto add_colsum = [&](const uint4 (&r)[4]) {
+		if constexpr (ALAYOUT == VITK_MN_MAJOR) {
+			if (do_colsum) {
+#pragma unroll
+				for (int i = 0; i < 4; ++i) {
+					const bf16x8 v = __builtin_bit_cast(bf16x8, r[i]);
+#pragma unroll
+					for (int e = 0; e < 8; ++e) csum[e] += (float)v[e];
+				}
+			}
+		}
+	};
+
 	bool by_dma = false;
 	if constexpr (ALAYOUT == VITK_K_MAJOR && BLAYOUT == VITK_K_MAJOR && !PATCH) by_dma = a.dma != 0;
 	if (by_dma) {
@@ -231,6 +255,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(BfArgs a) {
 		uint4 ra[4], rb[4];
 		load_tile<ALAYOUT, PATCH>(g, A, g.lda, m0, g.M, k_begin, k_end, ra, tid);
 		load_tile<BLAYOUT, false>(g, B, g.ldb, n0, g.N, k_begin, k_end, rb, tid);
+		add_colsum(ra);
 		store_tile<ALAYOUT>(smem, ra, tid);
 		store_tile<BLAYOUT>(smem + TILE_BYTES, rb, tid);
 		__syncthreads();
@@ -246,6 +271,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(BfArgs a) {
 			}
 			mma_tile(sa, sb);
 			if (more) {
+				add_colsum(ra);
 				char* da = smem + ((t + 1) & 1) * STAGE_BYTES;
 				store_tile<ALAYOUT>(da, ra, tid);
 				store_tile<BLAYOUT>(da + TILE_BYTES, rb, tid);
@@ -261,12 +287,40 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(BfArgs a) {
 	// runtime loop, and every index into acc[][] is a compile-time constant (a runtime index would move acc to scratch).
 	// acc[i][j][r]: m = wm + 16 i + (lane & 15), n = wn + 16 j + 4 (lane >> 4) + r
 	float* ct = reinterpret_cast<float*>(smem);
+	if constexpr (ALAYOUT == VITK_MN_MAJOR) {
+		if (do_colsum) {  // workgroup-uniform: the 16 row groups of a column combine through LDS (the stages are free now)
+#pragma unroll
+			for (int e = 0; e < 8; ++e) ct[(tid >> 4) * 128 + 8 * (tid & 15) + e] = csum[e];
+			__syncthreads();
+			if (tid < 128 && m0 + tid < g.M) {
+				float sum = 0.f;
+#pragma unroll
+				for (int r = 0; r < 16; ++r) sum += ct[r * 128 + tid];
+				if (a.cs_partials != nullptr) a.cs_partials[(int64_t)blockIdx.y * g.M + m0 + tid] = sum;
+				else if (a.splits > 1) atomicAdd(a.a_colsum + m0 + tid, sum);
+				else a.a_colsum[m0 + tid] += sum;  // the only workgroup that owns these rows
+			}
+			__syncthreads();
+		}
+	}
 #pragma unroll
 	for (int i = 0; i < 4; ++i)
 #pragma unroll
 		for (int j = 0; j < 4; ++j)
 			*reinterpret_cast<f32x4*>(ct + (wm + 16 * i + (lane & 15)) * CT_LD + wn + 16 * j + 4 * (lane >> 4)) = acc[i][j];
 	__syncthreads();
+	if (a.splits > 1 && a.partials != nullptr) {
+		// K-split partial tile into scratch, row-major 128 x 128 (512 contiguous bytes per row); split_reduce128_kernel
+		// adds the slices up: deterministic, and no float atomics (atomics of many workgroups on one address run one
+		// after the other at the memory side, about 0.2 us each)
+		float* dst = a.partials + ((int64_t)blockIdx.y * nwg + (int64_t)tm * a.tiles_n + tn) * (BM * BN);
+		for (int it = 0; it < (BM * BN / 4) / 256; ++it) {
+			const int v = it * 256 + tid;
+			const int row = v >> 5, c4 = v & 31;
+			*reinterpret_cast<f32x4*>(dst + row * BN + 4 * c4) = *reinterpret_cast<const f32x4*>(ct + row * CT_LD + 4 * c4);
+		}
+		return;
+	}
 	if (a.splits > 1) {
 		// split-K partial sums: float atomics, one dword per lane on consecutive addresses
 		float* cbase = reinterpret_cast<float*>(g.C);
@@ -285,6 +339,39 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(BfArgs a) {
 		if (m >= g.M || nb >= g.N) continue;
 		const f32x4 val = *reinterpret_cast<const f32x4*>(ct + row * CT_LD + 4 * c4);
 		store_frag<TOUT>(a, m, nb, val);
+	}
+}
+
+// C (+)= sum over the K slices of the partial tiles (blockIdx.y < ntile: one thread per 4 consecutive columns of a row),
+// and a_colsum += sum over the slices of the partial column sums (blockIdx.y == ntile).
+__global__ __launch_bounds__(256) void split_reduce128_kernel(const float* __restrict__ partials, float* __restrict__ C, int64_t M, int64_t N, int64_t ldc,
+	int tiles_n, int ntile, int splits, int accumulate, int vec4, const float* __restrict__ cs_partials, float* a_colsum) {
+	if ((int)blockIdx.y == ntile) {
+		if (cs_partials == nullptr) return;
+		for (int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x; m < M; m += (int64_t)gridDim.x * 256) {
+			float sum = 0.f;
+			for (int s = 0; s < splits; ++s) sum += cs_partials[(int64_t)s * M + m];
+			a_colsum[m] += sum;
+		}
+		return;
+	}
+	const int tile = blockIdx.y;
+	const int q = blockIdx.x * 256 + threadIdx.x;
+	const int row = q >> 5, c4 = q & 31;
+	const int64_t m = (int64_t)(tile / tiles_n) * BM + row;
+	const int64_t n = (int64_t)(tile % tiles_n) * BN + 4 * c4;
+	if (m >= M || n >= N) return;
+	const float* src = partials + (int64_t)tile * (BM * BN) + (int64_t)q * 4;
+	f32x4 v = *reinterpret_cast<const f32x4*>(src);
+	for (int s = 1; s < splits; ++s) v += *reinterpret_cast<const f32x4*>(src + (int64_t)s * ntile * (BM * BN));
+	float* c = C + m * ldc + n;
+	if (vec4 && n + 3 < N) {
+		if (accumulate) v += *reinterpret_cast<const f32x4*>(c);
+		*reinterpret_cast<f32x4*>(c) = v;
+	} else {
+#pragma unroll
+		for (int r = 0; r < 4; ++r)
+			if (n + r < N) c[r] = accumulate ? c[r] + v[r] : v[r];
 	}
 }
 
@@ -335,10 +422,10 @@ int vitk_gemm_bf16(const vitk_gemm_desc& d, hipStream_t st, bool* colsum_done) {
 		const int rc = vitk_gemm_bf16_256(d, st, colsum_done);
 		if (rc != VITK_ERR_UNSUPPORTED) return rc;
 	}
-	return vitk_gemm_bf16_128(d, st);
+	return vitk_gemm_bf16_128(d, st, colsum_done);
 }
 
-int vitk_gemm_bf16_128(const vitk_gemm_desc& d, hipStream_t st) {
+int vitk_gemm_bf16_128(const vitk_gemm_desc& d, hipStream_t st, bool* colsum_done) {
 	BfArgs a{};
 	a.g = make_gemm_dev(d);
 	a.tiles_m = (int)vitk_cdiv(d.M, BM);
@@ -357,7 +444,18 @@ int vitk_gemm_bf16_128(const vitk_gemm_desc& d, hipStream_t st) {
 	auto al16 = [](const void* p) { return p == nullptr || vitk_aligned(p, 16); };
 	a.vec4 = (d.N % 4 == 0) && (d.ldc % 4 == 0) && (d.ld_aux % 4 == 0) && (d.ld_out2 % 4 == 0) && al16(d.C) && al16(d.bias) && al16(d.gamma) && al16(d.pos) &&
 		al16(d.aux) && al16(d.out2);
-	if (a.splits > 1 && !d.accumulate) {
+	// MN-major A tiles pass through registers, where their column sums (the bias gradient) are formed on the way
+	const bool fuse_colsum = d.a_colsum != nullptr && d.a_layout == VITK_MN_MAJOR && d.patch_grid == 0;
+	if (fuse_colsum) a.a_colsum = d.a_colsum;
+	if (a.splits > 1) {
+		const int64_t tile_bytes = (int64_t)a.splits * tiles * BM * BN * (int64_t)sizeof(float);
+		const int64_t need = tile_bytes + (fuse_colsum ? (int64_t)a.splits * d.M * (int64_t)sizeof(float) : 0);
+		if (d.workspace != nullptr && d.workspace_bytes >= need && vitk_aligned(d.workspace, 16)) {
+			a.partials = reinterpret_cast<float*>(d.workspace);
+			if (fuse_colsum) a.cs_partials = a.partials + tile_bytes / (int64_t)sizeof(float);
+		}
+	}
+	if (a.splits > 1 && a.partials == nullptr && !d.accumulate) {
 		hipError_t e = hipMemset2DAsync(d.C, (size_t)d.ldc * sizeof(float), 0, (size_t)d.N * sizeof(float), (size_t)d.M, st);
 		if (e != hipSuccess) return VITK_ERR_HIP - (int)e;
 	}
@@ -365,9 +463,17 @@ int vitk_gemm_bf16_128(const vitk_gemm_desc& d, hipStream_t st) {
 	a.dma = !no_dma && d.patch_grid == 0 && d.a_layout == VITK_K_MAJOR && d.b_layout == VITK_K_MAJOR && d.K % BK == 0 && d.M >= 1 && d.N >= 1;
 	dim3 grid((unsigned)tiles, (unsigned)a.splits);
 	const bool patch = d.patch_grid > 0;
-	if (patch) return launch<VITK_K_MAJOR, VITK_K_MAJOR, true>(a, d.out_dtype, grid, st);
-	if (d.a_layout == VITK_K_MAJOR && d.b_layout == VITK_K_MAJOR) return launch<VITK_K_MAJOR, VITK_K_MAJOR, false>(a, d.out_dtype, grid, st);
-	if (d.a_layout == VITK_K_MAJOR && d.b_layout == VITK_MN_MAJOR) return launch<VITK_K_MAJOR, VITK_MN_MAJOR, false>(a, d.out_dtype, grid, st);
-	if (d.a_layout == VITK_MN_MAJOR && d.b_layout == VITK_MN_MAJOR) return launch<VITK_MN_MAJOR, VITK_MN_MAJOR, false>(a, d.out_dtype, grid, st);
-	return launch<VITK_MN_MAJOR, VITK_K_MAJOR, false>(a, d.out_dtype, grid, st);
+	int rc;
+	if (patch) rc = launch<VITK_K_MAJOR, VITK_K_MAJOR, true>(a, d.out_dtype, grid, st);
+	else if (d.a_layout == VITK_K_MAJOR && d.b_layout == VITK_K_MAJOR) rc = launch<VITK_K_MAJOR, VITK_K_MAJOR, false>(a, d.out_dtype, grid, st);
+	else if (d.a_layout == VITK_K_MAJOR && d.b_layout == VITK_MN_MAJOR) rc = launch<VITK_K_MAJOR, VITK_MN_MAJOR, false>(a, d.out_dtype, grid, st);
+	else if (d.a_layout == VITK_MN_MAJOR && d.b_layout == VITK_MN_MAJOR) rc = launch<VITK_MN_MAJOR, VITK_MN_MAJOR, false>(a, d.out_dtype, grid, st);
+	else rc = launch<VITK_MN_MAJOR, VITK_K_MAJOR, false>(a, d.out_dtype, grid, st);
+	if (rc == VITK_OK && a.partials != nullptr) {
+		hipLaunchKernelGGL(split_reduce128_kernel, dim3(BM * BN / 4 / 256, (unsigned)tiles + 1), dim3(256), 0, st, a.partials, reinterpret_cast<float*>(d.C), d.M, d.N,
+			d.ldc, a.tiles_n, (int)tiles, a.splits, d.accumulate, a.vec4, a.cs_partials, d.a_colsum);
+		VITK_CHECK_LAUNCH();
+	}
+	if (rc == VITK_OK && fuse_colsum && colsum_done != nullptr) *colsum_done = true;
+	return rc;
 }

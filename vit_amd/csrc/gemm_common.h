@@ -179,6 +179,6 @@ int vitk_gemm_generic(const vitk_gemm_desc& d, hipStream_t st);
 // *colsum_done is set when the kernel that ran also accumulated d.a_colsum
 int vitk_gemm_bf16(const vitk_gemm_desc& d, hipStream_t st, bool* colsum_done);
 bool vitk_gemm_bf16_ok(const vitk_gemm_desc& d);
-int vitk_gemm_bf16_128(const vitk_gemm_desc& d, hipStream_t st);  // the 128x128 kernel, whatever the shape
+int vitk_gemm_bf16_128(const vitk_gemm_desc& d, hipStream_t st, bool* colsum_done = nullptr);  // the 128x128 kernel, whatever the shape
 bool vitk_gemm_bf16_256_ok(const vitk_gemm_desc& d);  // large-tile LDS-DMA kernel (needs K % 64 == 0, M, N >= 256)
 int vitk_gemm_bf16_256(const vitk_gemm_desc& d, hipStream_t st, bool* colsum_done);
