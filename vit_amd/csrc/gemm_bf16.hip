@@ -342,7 +342,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(BfArgs a) {
 	}
 }
 
-// C (+)= sum over the K slices of the partial tiles (blockIdx.y < ntile: one thread per 4 consecutive columns of a row),
+// C (+)= sum over the K slices of the partial tiles (blockIdx.y < ntile),
 // and a_colsum += sum over the slices of the partial column sums (blockIdx.y == ntile).
 __global__ __launch_bounds__(256) void split_reduce128_kernel(const float* __restrict__ partials, float* __restrict__ C, int64_t M, int64_t N, int64_t ldc,
 	int tiles_n, int ntile, int splits, int accumulate, int vec4, const float* __restrict__ cs_partials, float* a_colsum) {
@@ -350,29 +350,53 @@ __global__ __launch_bounds__(256) void split_reduce128_kernel(const float* __res
 		if (cs_partials == nullptr) return;
 		for (int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x; m < M; m += (int64_t)gridDim.x * 256) {
 			float sum = 0.f;
-			for (int s = 0; s < splits; ++s) sum += cs_partials[(int64_t)s * M + m];
+			for (int s0 = 0; s0 < splits; s0 += 16) {
+				float t[16];
+#pragma unroll
+				for (int u = 0; u < 16; ++u) t[u] = s0 + u < splits ? cs_partials[(int64_t)(s0 + u) * M + m] : 0.f;
+#pragma unroll
+				for (int u = 0; u < 16; ++u) sum += t[u];
+			}
 			a_colsum[m] += sum;
 		}
 		return;
 	}
+	// one thread per output element: four times the loads in flight of a 16-byte-per-thread walk, which is what this
+	// short, latency-bound kernel (tens of slices of a few tiles) needs; a wave still reads 256 contiguous bytes
 	const int tile = blockIdx.y;
 	const int q = blockIdx.x * 256 + threadIdx.x;
-	const int row = q >> 5, c4 = q & 31;
+	const int row = q >> 7, col = q & 127;
 	const int64_t m = (int64_t)(tile / tiles_n) * BM + row;
-	const int64_t n = (int64_t)(tile % tiles_n) * BN + 4 * c4;
+	const int64_t n = (int64_t)(tile % tiles_n) * BN + col;
 	if (m >= M || n >= N) return;
-	const float* src = partials + (int64_t)tile * (BM * BN) + (int64_t)q * 4;
-	f32x4 v = *reinterpret_cast<const f32x4*>(src);
-	for (int s = 1; s < splits; ++s) v += *reinterpret_cast<const f32x4*>(src + (int64_t)s * ntile * (BM * BN));
-	float* c = C + m * ldc + n;
-	if (vec4 && n + 3 < N) {
-		if (accumulate) v += *reinterpret_cast<const f32x4*>(c);
-		*reinterpret_cast<f32x4*>(c) = v;
-	} else {
+	const float* src = partials + (int64_t)tile * (BM * BN) + q;
+	const int64_t step = (int64_t)ntile * (BM * BN);
+	// 16 slices requested before the first is used: the loop is a chain of memory round trips otherwise
+	float acc16[16];
 #pragma unroll
-		for (int r = 0; r < 4; ++r)
-			if (n + r < N) c[r] = accumulate ? c[r] + v[r] : v[r];
+	for (int u = 0; u < 16; ++u) acc16[u] = 0.f;
+	int s = 0;
+	for (; s + 15 < splits; s += 16) {
+		float t[16];
+#pragma unroll
+		for (int u = 0; u < 16; ++u) t[u] = src[(int64_t)(s + u) * step];
+#pragma unroll
+		for (int u = 0; u < 16; ++u) acc16[u] += t[u];
 	}
+	{
+		float t[16];
+#pragma unroll
+		for (int u = 0; u < 16; ++u) t[u] = s + u < splits ? src[(int64_t)(s + u) * step] : 0.f;
+#pragma unroll
+		for (int u = 0; u < 16; ++u) acc16[u] += t[u];
+	}
+#pragma unroll
+	for (int w = 8; w > 0; w >>= 1)
+#pragma unroll
+		for (int u = 0; u < w; ++u) acc16[u] += acc16[u + w];
+	const float v = acc16[0];
+	float* c = C + m * ldc + n;
+	*c = accumulate ? *c + v : v;
 }
 
 template <int AL, int BL, bool PATCH>
@@ -470,7 +494,7 @@ int vitk_gemm_bf16_128(const vitk_gemm_desc& d, hipStream_t st, bool* colsum_don
 	else if (d.a_layout == VITK_MN_MAJOR && d.b_layout == VITK_MN_MAJOR) rc = launch<VITK_MN_MAJOR, VITK_MN_MAJOR, false>(a, d.out_dtype, grid, st);
 	else rc = launch<VITK_MN_MAJOR, VITK_K_MAJOR, false>(a, d.out_dtype, grid, st);
 	if (rc == VITK_OK && a.partials != nullptr) {
-		hipLaunchKernelGGL(split_reduce128_kernel, dim3(BM * BN / 4 / 256, (unsigned)tiles + 1), dim3(256), 0, st, a.partials, reinterpret_cast<float*>(d.C), d.M, d.N,
+		hipLaunchKernelGGL(split_reduce128_kernel, dim3(BM * BN / 256, (unsigned)tiles + 1), dim3(256), 0, st, a.partials, reinterpret_cast<float*>(d.C), d.M, d.N,
 			d.ldc, a.tiles_n, (int)tiles, a.splits, d.accumulate, a.vec4, a.cs_partials, d.a_colsum);
 		VITK_CHECK_LAUNCH();
 	}
