@@ -72,7 +72,7 @@ struct DropAddF {
 // ---- column sum: out[n] += sum_m x[m*ld + n] ------------------------------------------------------
 // blockDim = (CX, RY): CX lanes own VEC consecutive columns each, RY row groups stream disjoint rows with 4
 // independent 16-byte loads in flight per lane; the row groups combine through LDS and the block issues ONE float
-// atomic per column, so a column sees only gridDim.y (<= 128) atomics.
+// atomic per column, so a column sees only gridDim.y (<= 64) atomics.
 template <typename T, int VEC>
 __global__ __launch_bounds__(1024) void colsum_kernel(const T* __restrict__ x, float* out, int64_t M, int64_t N, int64_t ld) {
 	extern __shared__ __attribute__((aligned(16))) float red[];  // [RY][CX * VEC]
@@ -120,12 +120,13 @@ int launch_colsum(const void* x, float* out, int64_t M, int64_t N, int64_t ld, h
 	const int vw = vec ? V : 1;
 	const int64_t chunks = vitk_cdiv(N, vw);
 	const int cx = (int)std::min<int64_t>(128, vitk_cdiv(chunks, 32) * 32);  // lanes along columns
-	static const int tpb = std::getenv("VITK_COLSUM_TPB") ? atoi(std::getenv("VITK_COLSUM_TPB")) : 1024;
-	static const int gymax = std::getenv("VITK_COLSUM_GY") ? atoi(std::getenv("VITK_COLSUM_GY")) : 128;
-	static const int rpt = std::getenv("VITK_COLSUM_RPT") ? atoi(std::getenv("VITK_COLSUM_RPT")) : 4;
-	const int ry = std::max(1, tpb / cx);
+	const int ry = std::max(1, 1024 / cx);
 	const unsigned gx = (unsigned)vitk_cdiv(chunks, cx);
-	const unsigned gy = (unsigned)std::max<int64_t>(1, std::min<int64_t>(vitk_cdiv(M, (int64_t)ry * rpt), gymax));
+	// Few workgroups along the rows: each ends with one float atomic per column, and atomics of different workgroups on
+	// one address run one after the other at the memory side (about 0.2 us each: 128 of them cost more than streaming
+	// the matrix).  64 (32 for a few MB) measured best from 33280 x 192 to 50432 x 3072.
+	const int64_t gy_cap = M * N * (int64_t)sizeof(T) < (16 << 20) ? 32 : 64;
+	const unsigned gy = (unsigned)std::max<int64_t>(1, std::min<int64_t>(vitk_cdiv(M, (int64_t)ry * 4), gy_cap));
 	const size_t lds = (size_t)ry * cx * vw * sizeof(float);
 	if (vec)
 		hipLaunchKernelGGL((colsum_kernel<T, V>), dim3(gx, gy), dim3(cx, ry), lds, st, (const T*)x, out, M, N, ld);
