@@ -229,6 +229,7 @@ struct BigArgs {
 	int tiles_m, tiles_n, splits, k_per_split;
 	int vec4, vec8;  // epilogue operands / outputs may be accessed 4-wide (8 / 16 bytes) resp. 8-wide (16 bytes bf16)
 	float* a_colsum;  // MN-major A: sum over k of A(m, k) is added here (bias gradient), or null
+	float* cs_partials;  // with partials: [split][tile column][row half][M] partial column sums for split_reduce_kernel instead of atomics
 	float* partials;  // K-split partial tiles [split][tile][wave][i][j][lane][4] (accumulator order), or null: float atomics into C
 #ifdef VITK_GEMM_STAMPS
 	long long* stamps;  // diagnostic builds only: [workgroup][round][8] timestamps of the persistent kernel
@@ -338,7 +339,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_256_kernel(BigArgs a) {
 	}
 
 	if constexpr (ALAYOUT == VITK_MN_MAJOR) {
-		if (do_colsum && m0 + (tid & 255) < g.M) atomicAdd(a.a_colsum + m0 + (tid & 255), csum);
+		if (do_colsum && m0 + (tid & 255) < g.M) {
+			// (float atomics of ~170 workgroup halves on one address run one after the other at the memory side)
+			if (a.cs_partials != nullptr) a.cs_partials[(((int64_t)split * a.tiles_n + tn) * 2 + (tid >> 8)) * g.M + m0 + (tid & 255)] = csum;
+			else atomicAdd(a.a_colsum + m0 + (tid & 255), csum);
+		}
 	}
 	STAMP(2);
 #ifdef VITK_GEMM_STAMPS
@@ -765,7 +770,32 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_256p_kernel(BigArgs a) 
 // C (+)= sum over the K slices of the partial tiles written above.  One thread per accumulator quad (4 consecutive
 // columns of one row): 16-byte loads at unit stride per slice, one 16-byte store.
 __global__ __launch_bounds__(256) void split_reduce_kernel(const float* __restrict__ partials, float* __restrict__ C, int64_t M, int64_t N, int64_t ldc, int tiles_n,
-	int ntile, int splits, int accumulate, int vec4) {
+	int ntile, int splits, int accumulate, int vec4, const float* __restrict__ cs_partials, float* a_colsum) {
+	if ((int)blockIdx.y == ntile) {  // the extra grid row: a_colsum[m] += sum of the partial column sums
+		if (cs_partials == nullptr) return;
+		// 16 columns per block, the parts dealt to 16 thread groups, so that a block has all its loads in flight at once
+		const int parts = splits * tiles_n * 2;
+		__shared__ float red[16][17];
+		const int grp = threadIdx.x >> 4, mi = threadIdx.x & 15;
+		for (int64_t mb = (int64_t)blockIdx.x * 16; mb < M; mb += (int64_t)gridDim.x * 16) {
+			const int64_t m = mb + mi;
+			float sum = 0.f;
+			if (m < M) {
+#pragma unroll 4
+				for (int p = grp; p < parts; p += 16) sum += cs_partials[(int64_t)p * M + m];
+			}
+			red[grp][mi] = sum;
+			__syncthreads();
+			if (grp == 0 && m < M) {
+				float tot = 0.f;
+#pragma unroll
+				for (int r = 0; r < 16; ++r) tot += red[r][mi];
+				a_colsum[m] += tot;
+			}
+			__syncthreads();
+		}
+		return;
+	}
 	const int tile = blockIdx.y;
 	const int q = blockIdx.x * 256 + threadIdx.x;  // quad index inside the tile: ((wave * 8 + i) * 4 + j) * 64 + lane
 	const int lane = q & 63, j = (q >> 6) & 3, i = (q >> 8) & 7, wave = q >> 11;
@@ -960,15 +990,20 @@ int vitk_gemm_bf16_256(const vitk_gemm_desc& d, hipStream_t st, bool* colsum_don
 	a.stagger = g_stagger;
 #endif
 	const int64_t need = (int64_t)a.splits * tiles * BM * BN * (int64_t)sizeof(float);
-	if (a.splits > 1 && d.workspace != nullptr && d.workspace_bytes >= need && vitk_aligned(d.workspace, 16)) a.partials = reinterpret_cast<float*>(d.workspace);
+	const bool cs_fused = d.a_colsum != nullptr && d.a_layout == VITK_MN_MAJOR && d.b_layout == VITK_MN_MAJOR && d.out_dtype == VITK_F32;
+	const int64_t cs_need = cs_fused ? (int64_t)a.splits * a.tiles_n * 2 * d.M * (int64_t)sizeof(float) : 0;
+	if (a.splits > 1 && d.workspace != nullptr && d.workspace_bytes >= need + cs_need && vitk_aligned(d.workspace, 16)) {
+		a.partials = reinterpret_cast<float*>(d.workspace);
+		if (cs_fused) a.cs_partials = a.partials + need / (int64_t)sizeof(float);
+	}
 	if (a.splits > 1 && a.partials == nullptr && !d.accumulate) {
 		hipError_t e = hipMemset2DAsync(d.C, (size_t)d.ldc * sizeof(float), 0, (size_t)d.N * sizeof(float), (size_t)d.M, st);
 		if (e != hipSuccess) return VITK_ERR_HIP - (int)e;
 	}
 	int rc = launch_variant(a, d, dim3((unsigned)(tiles * a.splits)), st);
 	if (rc == VITK_OK && a.partials != nullptr) {
-		hipLaunchKernelGGL(split_reduce_kernel, dim3(BM * BN / 4 / 256, (unsigned)tiles), dim3(256), 0, st, a.partials, reinterpret_cast<float*>(d.C), d.M, d.N, d.ldc, a.tiles_n,
-			(int)tiles, a.splits, d.accumulate, a.vec4);
+		hipLaunchKernelGGL(split_reduce_kernel, dim3(BM * BN / 4 / 256, (unsigned)tiles + 1), dim3(256), 0, st, a.partials, reinterpret_cast<float*>(d.C), d.M, d.N, d.ldc, a.tiles_n,
+			(int)tiles, a.splits, d.accumulate, a.vec4, a.cs_partials, d.a_colsum);
 		VITK_CHECK_LAUNCH();
 	}
 	// only the float32-output kernel with MN-major A (weight gradients) carries the column sums
