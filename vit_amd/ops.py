@@ -165,6 +165,25 @@ def _sink_done(p, sink):
 	return None
 
 
+class _Sinks:
+	"""The gradient sinks of one backward function's parameters: `buf(name)` is the buffer a kernel should add into (or
+	None), `ret(name, grad)` is what the function hands autograd for that parameter."""
+
+	def __init__(self, **params):
+		self.params = params
+		self.sinks = {n: _sink(p) for n, p in params.items()}
+
+	def buf(self, name):
+		s = self.sinks[name]
+		return s[0] if s is not None else None
+
+	def ret(self, name, grad):
+		p, s = self.params[name], self.sinks[name]
+		if p is None:
+			return None
+		return _sink_done(p, s) if s is not None else grad_as(grad, p)
+
+
 def f32(t):
 	"""float32 view/copy of a small parameter vector (norm weights, biases, LayerScale)."""
 	if t is None:
@@ -446,11 +465,20 @@ class LinearFn(torch.autograd.Function):
 			dy2 = du
 		wc = weight_as(w, dt)
 		dx = linear_dgrad(dy2, wc).reshape(xshape) if ctx.needs_input_grad[0] else None
-		dw = grad_as(linear_wgrad(dy2, x2), w) if ctx.needs_input_grad[1] else None
-		db = grad_as(colsum(dy2), b) if (b is not None and ctx.needs_input_grad[2]) else None
+		want_w, want_b = ctx.needs_input_grad[1], b is not None and ctx.needs_input_grad[2]
+		sk = _Sinks(w=w if want_w else None, b=b if want_b else None)
+		dw = db = None
+		if want_w and want_b:  # the bias gradient rides in the weight-gradient kernel
+			dw, db = linear_wgrad(dy2, x2, bias_grad=True, dw_out=sk.buf("w"), db_out=sk.buf("b"))
+		elif want_w:
+			dw = linear_wgrad(dy2, x2, dw_out=sk.buf("w"))
+		elif want_b:
+			db = colsum(dy2)
+			if sk.buf("b") is not None:
+				sk.buf("b").add_(db)
 		if dx is not None and dx.dtype != xdtype:
 			dx = cast(dx, xdtype)
-		return dx, dw, db, None
+		return dx, sk.ret("w", dw), sk.ret("b", db), None
 
 
 class NormFn(torch.autograd.Function):
@@ -472,11 +500,12 @@ class NormFn(torch.autograd.Function):
 		x2, weight, mean, rstd = ctx.saved_tensors
 		xshape, xdtype, bias, kind, unit_offset = ctx.meta
 		dy2 = _flat(cast(dy, x2.dtype))
-		dx, dw, db = norm_bwd(dy2, x2, f32(weight), mean, rstd, kind, unit_offset)
+		sk = _Sinks(w=weight, b=bias)
+		dx, dw, db = norm_bwd(dy2, x2, f32(weight), mean, rstd, kind, unit_offset, dw_out=sk.buf("w"), db_out=sk.buf("b"))
 		dx = dx.reshape(xshape)
 		if dx.dtype != xdtype:
 			dx = cast(dx, xdtype)
-		return dx, grad_as(dw, weight), grad_as(db, bias) if bias is not None else None, None, None, None
+		return dx, sk.ret("w", dw), sk.ret("b", db), None, None, None
 
 
 def _ffn_forward(x2, w1, b1, w2, b2, act, gated, residual=None, gamma=None, drop1=(0.0, 0), drop_out=()):
@@ -528,12 +557,14 @@ class FeedForwardFn(torch.autograd.Function):
 		x2, u, a, w1, w2 = ctx.saved_tensors
 		xshape, xdtype, b1, b2, act, gated, dt = ctx.meta
 		dy2 = _flat(cast(dy, dt))
-		dx, dw1, db1, dw2, db2 = _ffn_backward(dy2, x2, u, a, weight_as(w1, dt), weight_as(w2, dt), act, gated, ctx.needs_input_grad[0])
+		sk = _Sinks(w1=w1, b1=b1, w2=w2, b2=b2)
+		dx, dw1, db1, dw2, db2 = _ffn_backward(dy2, x2, u, a, weight_as(w1, dt), weight_as(w2, dt), act, gated, ctx.needs_input_grad[0],
+			outs=(sk.buf("w1"), sk.buf("b1"), sk.buf("w2"), sk.buf("b2")))
 		if dx is not None:
 			dx = dx.reshape(xshape)
 			if dx.dtype != xdtype:
 				dx = cast(dx, xdtype)
-		return dx, grad_as(dw1, w1), grad_as(db1, b1), grad_as(dw2, w2), grad_as(db2, b2), None, None
+		return dx, sk.ret("w1", dw1), sk.ret("b1", db1), sk.ret("w2", dw2), sk.ret("b2", db2), None, None
 
 
 def _mha_forward(x2, wqkv, wo, bo, B, S, n_head, residual=None, gamma=None, drop=(0.0, 0), drop_out=()):
@@ -578,12 +609,14 @@ class MHAFn(torch.autograd.Function):
 		x2, qkv, o, lse, wqkv, wo = ctx.saved_tensors
 		(B, S, d), xdtype, bo, n_head, dt, drop = ctx.meta
 		dy2 = _flat(cast(dy, dt))
-		dx, dwqkv, dwo, dbo = _mha_backward(dy2, x2, qkv, o, lse, weight_as(wqkv, dt), weight_as(wo, dt), B, S, n_head, ctx.needs_input_grad[0], drop=drop)
+		sk = _Sinks(wqkv=wqkv, wo=wo, bo=bo)
+		dx, dwqkv, dwo, dbo = _mha_backward(dy2, x2, qkv, o, lse, weight_as(wqkv, dt), weight_as(wo, dt), B, S, n_head, ctx.needs_input_grad[0],
+			outs=(sk.buf("wqkv"), sk.buf("wo"), sk.buf("bo")), drop=drop)
 		if dx is not None:
 			dx = dx.reshape(B, S, d)
 			if dx.dtype != xdtype:
 				dx = cast(dx, xdtype)
-		return dx, grad_as(dwqkv, wqkv), grad_as(dwo, wo), grad_as(dbo, bo), None, None
+		return dx, sk.ret("wqkv", dwqkv), sk.ret("wo", dwo), sk.ret("bo", dbo), None, None
 
 
 class ViTBlockFn(torch.autograd.Function):
@@ -1030,15 +1063,16 @@ class ConvAttentionFn(torch.autograd.Function):
 		drop = cfg[6] if len(cfg) > 6 else (0.0, 0)
 		dh = C // n_head
 		dy2 = _flat(cast(dy, dt))
-		dwo, dbo = linear_wgrad(dy2, o, bias_grad=True)
+		sk = _Sinks(wq=wq, bq=bq, wk=wk, bk=bk, wv=wv, bv=bv, wo=wo, bo=bo)
+		dwo, dbo = linear_wgrad(dy2, o, bias_grad=True, dw_out=sk.buf("wo"), db_out=sk.buf("bo"))
 		do = linear_dgrad(dy2, weight_as(wo, dt))
 		dq, dk1, dv1 = torch.empty_like(q), torch.empty_like(k1), torch.empty_like(v1)
 		attention_bwd(do, q, k1, v1, o, lse, dq, dk1, dv1, Bn, n_head, S, Skv, dh, drop=drop)
 		dk0, dck = dwconv_bwd(dk1, k0, weight_as(ck, dt), Bn, H, W, C, ks, stride, pad)
 		dv0, dcv = dwconv_bwd(dv1, v0, weight_as(cv, dt), Bn, H, W, C, ks, stride, pad)
-		dwq, dbq = linear_wgrad(dq, x2, bias_grad=True)
-		dwk, dbk = linear_wgrad(dk0, x2, bias_grad=True)
-		dwv, dbv = linear_wgrad(dv0, x2, bias_grad=True)
+		dwq, dbq = linear_wgrad(dq, x2, bias_grad=True, dw_out=sk.buf("wq"), db_out=sk.buf("bq"))
+		dwk, dbk = linear_wgrad(dk0, x2, bias_grad=True, dw_out=sk.buf("wk"), db_out=sk.buf("bk"))
+		dwv, dbv = linear_wgrad(dv0, x2, bias_grad=True, dw_out=sk.buf("wv"), db_out=sk.buf("bv"))
 		dx = None
 		if ctx.needs_input_grad[0]:
 			# dx = dq Wq + dk0 Wk + dv0 Wv: the second and third GEMM add onto the first through the residual epilogue (C aliases aux)
@@ -1048,8 +1082,8 @@ class ConvAttentionFn(torch.autograd.Function):
 			dx = dx.reshape(Bn, S, C)
 			if dx.dtype != xdtype:
 				dx = cast(dx, xdtype)
-		return (dx, grad_as(dwq, wq), grad_as(dbq, bq), grad_as(dwk, wk), grad_as(dbk, bk), grad_as(dwv, wv), grad_as(dbv, bv),
-			grad_as(dck, ck), grad_as(dcv, cv), grad_as(dwo, wo), grad_as(dbo, bo), None)
+		return (dx, sk.ret("wq", dwq), sk.ret("bq", dbq), sk.ret("wk", dwk), sk.ret("bk", dbk), sk.ret("wv", dwv), sk.ret("bv", dbv),
+			grad_as(dck, ck), grad_as(dcv, cv), sk.ret("wo", dwo), sk.ret("bo", dbo), None)
 
 
 class MBConvFn(torch.autograd.Function):
