@@ -469,7 +469,8 @@ int vitk_gemm_bf16_128(const vitk_gemm_desc& d, hipStream_t st, bool* colsum_don
 	a.vec4 = (d.N % 4 == 0) && (d.ldc % 4 == 0) && (d.ld_aux % 4 == 0) && (d.ld_out2 % 4 == 0) && al16(d.C) && al16(d.bias) && al16(d.gamma) && al16(d.pos) &&
 		al16(d.aux) && al16(d.out2);
 	// MN-major A tiles pass through registers, where their column sums (the bias gradient) are formed on the way
-	const bool fuse_colsum = d.a_colsum != nullptr && d.a_layout == VITK_MN_MAJOR && d.patch_grid == 0;
+	static const bool no_fused_cs = getenv("VITK_NO_FUSED_COLSUM128") != nullptr;  // A-B switch
+	const bool fuse_colsum = !no_fused_cs && d.a_colsum != nullptr && d.a_layout == VITK_MN_MAJOR && d.patch_grid == 0;
 	if (fuse_colsum) a.a_colsum = d.a_colsum;
 	if (a.splits > 1) {
 		const int64_t tile_bytes = (int64_t)a.splits * tiles * BM * BN * (int64_t)sizeof(float);
