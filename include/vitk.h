@@ -119,6 +119,9 @@ typedef struct vitk_gemm_desc {
 	                              The mask is the one vitk_dropout(p, seed) applies to a contiguous [M, N] tensor.
 	                              Any other epilogue with drop_p != 0: VITK_ERR_UNSUPPORTED. */
 	uint64_t drop_seed[2];
+	int64_t drop_row0;         /* the mask index of this problem's row 0 is drop_row0 * N: a caller that splits one
+	                              [M, N] product into row blocks passes each block's first row, so that the blocks
+	                              draw the mask of the whole tensor */
 } vitk_gemm_desc;
 
 int vitk_gemm(const vitk_gemm_desc* desc, void* stream);

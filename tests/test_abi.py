@@ -32,9 +32,9 @@ def test_gemm_desc_layout_matches_header():
 	import ctypes
 	import vit_amd._lib as L
 	# 3 pointers, 6 int64, 12 int32, 3 pointers, pointer + int64, pointer + int64
-	# ... then 2 floats + 2 uint64 (fused dropout)
-	assert ctypes.sizeof(L.GemmDesc) == 3 * 8 + 6 * 8 + 12 * 4 + 3 * 8 + 16 + 16 + 8 + 16 + 8 + 16
-	assert L.GemmDesc.drop_seed.offset == ctypes.sizeof(L.GemmDesc) - 16
+	# ... then 2 floats + 2 uint64 + 1 int64 (fused dropout)
+	assert ctypes.sizeof(L.GemmDesc) == 3 * 8 + 6 * 8 + 12 * 4 + 3 * 8 + 16 + 16 + 8 + 16 + 8 + 16 + 8
+	assert L.GemmDesc.drop_seed.offset == ctypes.sizeof(L.GemmDesc) - 24
 	assert L.GemmDesc.bias.offset == 3 * 8 + 6 * 8 + 12 * 4
 
 

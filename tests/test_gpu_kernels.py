@@ -152,6 +152,25 @@ def test_gemm_fused_dropout(gpu, dtype, M, N, K):
 		ops.gemm(x, w, torch.empty((M, N), dtype=dtype, device=gpu), M, N, K, K, K, N, drop=(d1,))  # no epilogue to carry it
 
 
+def test_gemm_fused_dropout_across_the_row_split(gpu):
+	"""N = 768, K >= 1536 with a partly filled last round of 256 x 256 tiles: the call runs as two row blocks on two
+	kernels; the second block must draw the mask of ITS rows of the whole tensor (drop_row0), or the backward pass, which
+	masks the gradient of the whole tensor, would disagree with the forward pass on those rows."""
+	from vit_amd import ops
+	dtype = torch.bfloat16
+	M, N, K = 300 * 256 // 3, 768, 1536  # 100 x 3 tiles on 256 CUs: one whole round + 44 tiles
+	x, _ = rnd((M, K), dtype, gpu, 0.5, seed=1)
+	w, _ = rnd((N, K), dtype, gpu, 0.05, seed=2)
+	res, rr = rnd((M, N), dtype, gpu, seed=4)
+	d1 = (0.3, 991)
+	plain = ops.linear_fwd(x, w, None).cpu().double()  # the same two kernels without dropout
+	y = ops.linear_fwd(x, w, None, residual=res, drop=(d1,))
+	m1 = O.dropout_multiplier(d1[1], d1[0], M * N).reshape(M, N)
+	assert relerr(y, rr + plain * m1) < TOL[dtype]
+	tail = slice(M - 2000, M)  # rows of the second block on their own: a mask restarted at row 0 would fail here
+	assert relerr(y[tail], (rr + plain * m1)[tail]) < TOL[dtype]
+
+
 @pytest.mark.parametrize("act", ["gelu", "silu"])
 def test_gemm_more_tiles_than_cus(gpu, act):
 	"""bf16 GEMMs with more 256x256 output tiles than the GPU has CUs (ragged last tile row and column): the

@@ -36,7 +36,7 @@ class GemmDesc(ctypes.Structure):
 		("out2", c_void_p), ("ld_out2", c_int64),
 		("a_colsum", c_void_p),
 		("workspace", c_void_p), ("workspace_bytes", c_int64),
-		("drop_p", c_float * 2), ("drop_seed", ctypes.c_uint64 * 2),
+		("drop_p", c_float * 2), ("drop_seed", ctypes.c_uint64 * 2), ("drop_row0", c_int64),
 	]
 
 

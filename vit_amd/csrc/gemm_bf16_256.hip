@@ -949,6 +949,7 @@ static int split_off_partial_round(const vitk_gemm_desc& d, hipStream_t st, bool
 	d2.C = reinterpret_cast<char*>(d.C) + (size_t)M1 * d.ldc * e;
 	if (d.aux != nullptr) d2.aux = reinterpret_cast<const char*>(d.aux) + (size_t)M1 * d.ld_aux * e;
 	if (d.out2 != nullptr) d2.out2 = reinterpret_cast<char*>(d.out2) + (size_t)M1 * d.ld_out2 * e;
+	d2.drop_row0 = d.drop_row0 + M1;  // the second block draws the mask of its rows in the whole tensor
 	*handled = true;
 	bool unused = false;
 	int rc = vitk_gemm_bf16_256(d1, st, &unused);

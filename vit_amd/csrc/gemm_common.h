@@ -23,6 +23,7 @@ struct GemmDev {
 	int64_t ld_out2;
 	DropKey drop[2];   // fused dropout masks (thr16 == 0: off)
 	float drop_scale;  // product of the active masks' 1 / keep-probability
+	int64_t drop_m0;   // row offset of the mask index (this problem is a row block of a larger tensor)
 };
 
 static inline GemmDev make_gemm_dev(const vitk_gemm_desc& d) {
@@ -38,6 +39,7 @@ static inline GemmDev make_gemm_dev(const vitk_gemm_desc& d) {
 	g.bias = d.bias; g.gamma = d.gamma; g.pos = d.pos;
 	g.aux = d.aux; g.ld_aux = d.ld_aux; g.out2 = d.out2; g.ld_out2 = d.ld_out2;
 	g.drop_scale = 1.f;
+	g.drop_m0 = d.drop_row0;
 	int nd = 0;
 	for (int i = 0; i < 2; ++i) {
 		if (d.drop_p[i] > 0.f) {  // active masks are packed to the front: drop[0].thr16 == 0 means none
@@ -68,7 +70,7 @@ __device__ __forceinline__ int64_t out_row(const GemmDev& g, int64_t m) { return
 // indexed by the logical element m * g.N + n.  Call only when g.drop[0].thr16 != 0.
 template <int N>
 __device__ __forceinline__ void drop_keep_n(const GemmDev& g, int64_t m, int64_t n0, float (&keep)[N]) {
-	const uint64_t i0 = (uint64_t)(m * g.N + n0);
+	const uint64_t i0 = (uint64_t)((m + g.drop_m0) * g.N + n0);
 	if ((N & (N - 1)) == 0 && N >= 2 && (i0 & (N - 1)) == 0) {
 		// an aligned group of N: one hash per two elements and mask, and pair + j cannot carry into the upper index word
 		const uint64_t pair0 = i0 >> 1;
@@ -105,7 +107,7 @@ __device__ __forceinline__ void epi_store1(const GemmDev& g, int64_t m, int64_t 
 	// fused dropout: multiplier of the masked quantity (the mask is indexed by the logical element m * N + n)
 	float keep = 1.f;
 	if (g.drop[0].thr16) {
-		const uint64_t i = (uint64_t)(m * g.N + n);
+		const uint64_t i = (uint64_t)((m + g.drop_m0) * g.N + n);
 		keep = drop_keep(g.drop[0], i) && (!g.drop[1].thr16 || drop_keep(g.drop[1], i)) ? g.drop_scale : 0.f;
 	}
 	if (epilogue == VITK_EPI_ACT) {

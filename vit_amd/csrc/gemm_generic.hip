@@ -115,6 +115,7 @@ extern "C" int vitk_gemm(const vitk_gemm_desc* desc, void* stream) {
 	VITK_REQUIRE(d.out_dtype == VITK_F32 || d.out_dtype == VITK_BF16, VITK_ERR_DTYPE);
 	VITK_REQUIRE(!(d.in_dtype == VITK_F32 && d.out_dtype == VITK_BF16), VITK_ERR_DTYPE);
 	if (d.a_colsum != nullptr) VITK_REQUIRE(d.a_layout == VITK_MN_MAJOR && d.patch_grid == 0, VITK_ERR_UNSUPPORTED);
+	VITK_REQUIRE(d.drop_row0 >= 0, VITK_ERR_SHAPE);
 	for (int i = 0; i < 2; ++i) {
 		VITK_REQUIRE(d.drop_p[i] >= 0.f && d.drop_p[i] < 1.f, VITK_ERR_SHAPE);
 		if (d.drop_p[i] > 0.f) VITK_REQUIRE(d.epilogue != VITK_EPI_NONE && d.tokens_per_image == 0 && !d.accumulate, VITK_ERR_UNSUPPORTED);
