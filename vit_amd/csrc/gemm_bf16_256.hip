@@ -932,6 +932,7 @@ static int split_off_partial_round(const vitk_gemm_desc& d, hipStream_t st, bool
 	*handled = false;
 	static const bool off = std::getenv("VITK_NO_TAIL_SPLIT") != nullptr;
 	if (off || d.out_dtype != VITK_BF16 || d.a_layout != VITK_K_MAJOR || d.accumulate || d.K < 1536) return VITK_OK;
+	if (d.patch_grid > 0 || d.tokens_per_image > 0) return VITK_OK;  // rows are not plain rows of A / C there
 	const int64_t P = persistent_blocks();
 	const int64_t tiles_m = vitk_cdiv(d.M, BM), tiles_n = vitk_cdiv(d.N, BN);
 	const int64_t tiles = tiles_m * tiles_n;
