@@ -304,7 +304,8 @@ def test_norms(gpu, dtype, kind, rows, d):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("B,h,Sq,Skv,dh", [(2, 3, 65, 65, 64), (2, 12, 197, 197, 64), (3, 4, 17, 17, 12), (2, 2, 50, 13, 24), (2, 6, 4, 1, 64), (1, 1, 300, 300, 64), (2, 2, 16, 4, 32)])
+@pytest.mark.parametrize("B,h,Sq,Skv,dh", [(2, 3, 65, 65, 64), (2, 12, 197, 197, 64), (3, 4, 17, 17, 12), (2, 2, 50, 13, 24), (2, 6, 4, 1, 64), (1, 1, 300, 300, 64), (2, 2, 16, 4, 32),
+	(70, 12, 65, 65, 64), (67, 9, 40, 24, 64)])  # the last two: more (batch, head) pairs than CUs (several pairs per workgroup, ragged last workgroup)
 def test_attention(gpu, dtype, B, h, Sq, Skv, dh):
 	from vit_amd import ops
 	d = h * dh
@@ -334,7 +335,8 @@ def test_attention(gpu, dtype, B, h, Sq, Skv, dh):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("B,h,Sq,Skv,dh,p", [(2, 12, 197, 197, 64, 0.3), (2, 3, 65, 65, 64, 0.1), (2, 2, 50, 13, 24, 0.3), (1, 2, 300, 300, 64, 0.5), (2, 2, 64, 16, 32, 0.3)])
+@pytest.mark.parametrize("B,h,Sq,Skv,dh,p", [(2, 12, 197, 197, 64, 0.3), (2, 3, 65, 65, 64, 0.1), (2, 2, 50, 13, 24, 0.3), (1, 2, 300, 300, 64, 0.5), (2, 2, 64, 16, 32, 0.3),
+	(70, 12, 65, 65, 64, 0.3), (67, 9, 40, 24, 64, 0.2)])  # the last two: more (batch, head) pairs than CUs, so a workgroup walks several pairs
 def test_attention_dropout(gpu, dtype, B, h, Sq, Skv, dh, p):
 	"""Attention with dropout on the probabilities (the reference's training path, layers/attention.py:41,86): the
 	kernels' mask is regenerated on the CPU and handed to the oracle, so forward and all three gradients are compared
