@@ -152,6 +152,33 @@ def test_gemm_fused_dropout(gpu, dtype, M, N, K):
 		ops.gemm(x, w, torch.empty((M, N), dtype=dtype, device=gpu), M, N, K, K, K, N, drop=(d1,))  # no epilogue to carry it
 
 
+def test_gemm_row_split_last_round(gpu):
+	"""N = 768, K >= 1536, 300 tiles of 256 x 256 on 256 CUs: the whole round runs on the persistent kernel, the 44
+	remaining tiles' rows on the 128 x 128 kernel.  Both blocks against the float64 product, with every epilogue that
+	carries a row-indexed operand (residual, pre-activation in, pre-activation out)."""
+	from vit_amd import ops
+	import vit_amd._lib as L
+	dtype = torch.bfloat16
+	M, N, K = 25600, 768, 1536
+	x, xr = rnd((M, K), dtype, gpu, 0.5, seed=1)
+	w, wr = rnd((N, K), dtype, gpu, 0.05, seed=2)
+	bias = torch.randn(N, generator=torch.Generator().manual_seed(3))
+	res, rr = rnd((M, N), dtype, gpu, seed=4)
+	ref = xr @ wr.t() + bias.double()
+	for rows in (slice(0, M), slice(M - 3000, M)):  # the whole result, and the second block on its own
+		y = ops.linear_fwd(x, w, bias.to(gpu), residual=res)
+		assert relerr(y[rows], (rr + ref)[rows]) < TOL[dtype]
+		a, pre = ops.linear_fwd(x, w, bias.to(gpu), act=L.ACT_CODES["gelu"], save_pre=True)
+		assert relerr(pre[rows], ref[rows]) < TOL[dtype]
+		assert relerr(a[rows], O.act_fwd(pre.cpu().double(), "gelu")[rows]) < TOL[dtype]
+	dy, dyr = rnd((M, K), dtype, gpu, seed=6)   # gradient of a [M, K]-wide next layer whose weight is [K, N]
+	w2, w2r = rnd((K, N), dtype, gpu, 0.05, seed=7)
+	ops.weights_changed()
+	du = ops.linear_dgrad(dy, w2, act=L.ACT_CODES["gelu"], pre=pre)
+	want = (dyr @ w2r) * O.act_grad(pre.cpu().double(), "gelu")
+	assert relerr(du, want) < TOL[dtype] and relerr(du[M - 3000:], want[M - 3000:]) < TOL[dtype]
+
+
 def test_gemm_fused_dropout_across_the_row_split(gpu):
 	"""N = 768, K >= 1536 with a partly filled last round of 256 x 256 tiles: the call runs as two row blocks on two
 	kernels; the second block must draw the mask of ITS rows of the whole tensor (drop_row0), or the backward pass, which
