@@ -300,7 +300,8 @@ def test_dgrad_transposed_weight_path(gpu):
 
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("kind", ["layernorm", "rmsnorm"])
-@pytest.mark.parametrize("rows,d", [(37, 768), (9, 192), (5, 40), (3, 50), (11, 2048), (1, 768), (1030, 768), (9, 256), (6, 1280)])
+@pytest.mark.parametrize("rows,d", [(37, 768), (9, 192), (5, 40), (3, 50), (11, 2048), (1, 768), (1030, 768), (9, 256), (6, 1280),
+	(20001, 768), (40003, 192), (36000, 50)])  # the last three: more rows than waves in the grid (every wave loops, odd tails)
 def test_norms(gpu, dtype, kind, rows, d):
 	from vit_amd import ops
 	x, xr = rnd((rows, d), dtype, gpu, 1.5, seed=1)
