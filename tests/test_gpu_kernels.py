@@ -497,3 +497,34 @@ def test_adamw_golden(gpu):
 			meta["eps"], meta["weight_decay"], step + 1, 1.0, L.stream()))
 		assert relerr(p, g[f"p{step + 1}"]) < 1e-5
 	assert torch.equal(p16, p.to(torch.bfloat16))
+
+
+def test_streaming_kernels_at_sizes_that_loop(gpu):
+	"""AdamW and dropout over several million elements (odd counts): the grids are capped, so every thread walks a
+	stride loop that the small golden cases never enter.  AdamW against the update formula of torch.optim.AdamW
+	(main.py:100 there) evaluated by the oracle in float64; the dropout mask against the oracle's, bit for bit."""
+	import vit_amd._lib as L
+	from vit_amd import ops
+	lib = L.load()
+	n = 6_000_003
+	gen = torch.Generator().manual_seed(0)
+	p0 = torch.randn(n, generator=gen)
+	g0 = torch.randn(n, generator=gen) * 0.1
+	m0 = torch.randn(n, generator=gen) * 0.01
+	v0 = torch.rand(n, generator=gen) * 0.01
+	mask = (torch.rand(n, generator=gen) < 0.7).to(torch.uint8)  # weight decay on 70 % of the elements
+	p, g, m, v = (t.to(gpu).clone() for t in (p0, g0, m0, v0))
+	p16 = torch.empty(n, dtype=torch.bfloat16, device=gpu)
+	lr, b1, b2, eps, wd, step, gscale = 1e-3, 0.9, 0.999, 1e-8, 0.05, 7, 0.5
+	L.check(lib.vitk_adamw(L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), L.ptr(mask.to(gpu)), L.ptr(p16), n, lr, b1, b2, eps, wd, step, gscale, L.stream()))
+	want_p = torch.empty(n, dtype=torch.float64)
+	dec = mask.bool()
+	for sel, w in ((dec, wd), (~dec, 0.0)):
+		pp, mm, vv = O.adamw_step(p0[sel].double(), g0[sel].double() * gscale, m0[sel].double(), v0[sel].double(), step, lr, b1, b2, eps, w)
+		want_p[sel] = pp
+	assert relerr(p, want_p) < 1e-6
+	assert torch.equal(p16, p.to(torch.bfloat16))
+	# dropout over the same count: stride loop + the last, unpaired element
+	x = torch.ones(n, device=gpu)
+	got = ops.dropout_add(x, None, 0.3, 424242)
+	assert torch.equal(got.cpu().double() != 0, O.dropout_multiplier(424242, 0.3, n) != 0)
