@@ -187,3 +187,35 @@ def test_module_by_module_functions_write_their_gradient_sinks(gpu):
 	for k, p in sunk.named_parameters():
 		assert relerr(p.grad, 2 * want[k]) < 5e-2, k
 	ops.clear_grad_sinks()
+
+
+def test_trainer_steps_like_torch_adamw_with_the_reference_groups(gpu):
+	"""dp.Trainer (flat buffers, fused device-side AdamW, weight-decay mask from the reference's name rule, bf16 and
+	transposed weight copies refreshed per step) against torch.optim.AdamW over get_param_groups (utils.py:102-121,
+	main.py:100 there) on a twin model: same float32 forward / backward kernels, so only the optimizer differs."""
+	from conftest import relerr
+	from vit_amd import dp, ops
+	ops.clear_grad_sinks()
+	g = torch.Generator().manual_seed(21)
+	xs = [torch.randn(8, 3, 16, 16, generator=g).to(gpu) for _ in range(4)]
+	ys = [torch.randint(0, 10, (8,), generator=g).to(gpu) for _ in range(4)]
+	a, b = _model(gpu), _model(gpu)
+	dec = [p for n, p in b.named_parameters() if not (n.endswith("bias") or "norm" in n.lower() or "layerscale" in n.lower())]
+	nod = [p for n, p in b.named_parameters() if (n.endswith("bias") or "norm" in n.lower() or "layerscale" in n.lower())]
+	assert dec and nod
+	opt = torch.optim.AdamW([{"params": dec, "weight_decay": 0.05}, {"params": nod, "weight_decay": 0.0}], lr=3e-3, betas=(0.9, 0.999), eps=1e-8)
+	tr = dp.Trainer(a, lr=3e-3, weight_decay=0.05)
+	for x, y in zip(xs, ys):
+		tr.zero_grad()
+		ops.cross_entropy(a(x), y).backward()
+		tr.step()
+		opt.zero_grad()
+		ops.cross_entropy(b(x), y).backward()
+		opt.step()
+		ops.invalidate_casts()
+		ops.weights_changed()  # the stock optimizer wrote b's weights behind the kernels' cached copies
+		for (n, p), q in zip(a.named_parameters(), b.parameters()):
+			assert relerr(p, q) < 2e-5, n
+	# the bf16 copy the next forward reads is the rounded float32 parameter
+	assert torch.equal(tr.opt.shadow, tr.flat.param.to(torch.bfloat16))
+	ops.clear_grad_sinks()
