@@ -528,3 +528,25 @@ def test_streaming_kernels_at_sizes_that_loop(gpu):
 	x = torch.ones(n, device=gpu)
 	got = ops.dropout_add(x, None, 0.3, 424242)
 	assert torch.equal(got.cpu().double() != 0, O.dropout_multiplier(424242, 0.3, n) != 0)
+
+
+@pytest.mark.parametrize("B,C", [(5000, 1000), (70000, 10), (33, 1001), (1, 7)])
+def test_ce_kd_loss_shapes(gpu, B, C):
+	"""The DeiT loss kernel (deit_trainer.py:23-52 there) beyond the golden cases: ImageNet's class count, more rows than
+	the grid holds, a class count that is no multiple of the vector width, one row.  Float32 against the oracle."""
+	from vit_amd import ops
+	g = torch.Generator().manual_seed(B + C)
+	s0 = torch.randn(B, C, generator=g) * 2.0
+	t0 = torch.randn(B, C, generator=g) * 3.0
+	y = torch.randint(0, C, (B,), generator=g)
+	for alpha, tau, ls in ((0.5, 2.0, 0.1), (0.0, 1.0, 0.0)):
+		s = s0.to(gpu).requires_grad_(True)
+		loss = ops.deit_loss(s, y.to(gpu), t0.to(gpu), alpha, tau, ls)
+		loss.backward()
+		assert relerr(loss, O.deit_loss_fwd(s0.double(), y, t0.double(), alpha, tau, ls)) < 1e-4
+		assert relerr(s.grad, O.deit_loss_bwd(s0.double(), y, t0.double(), alpha, tau, ls)) < 1e-4
+	s = s0.to(gpu).requires_grad_(True)
+	l2 = ops.cross_entropy(s, y.to(gpu), 0.1)
+	l2.backward()
+	assert relerr(l2, O.cross_entropy_fwd(s0.double(), y, 0.1)) < 1e-4
+	assert relerr(s.grad, O.cross_entropy_bwd(s0.double(), y, 0.1)) < 1e-4
