@@ -378,3 +378,34 @@ def test_full_size_block_with_dropout_matches_composition(gpu):
 	assert relerr(y1[-4:], y2[-4:]) < 2e-2 and relerr(dx1[-4:], dx2[-4:]) < 4e-2
 	for k in g1:
 		assert relerr(g1[k], g2[k]) < 4e-2, k
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("ci,co,k,s,p,hw,B", [(3, 64, 7, 4, 2, 64, 48), (64, 192, 3, 2, 1, 28, 40), (24, 40, 3, 2, 1, 15, 9), (3, 96, 7, 4, 2, 224, 4)])
+def test_conv_embedding_many_rows(gpu, dtype, ci, co, k, s, p, hw, B):
+	"""ConvEmbedding (layers/embeddings.py:18-28 there: Conv2d without bias -> BatchNorm2d -> tokens) at sizes where the
+	im2col, BatchNorm-statistics and column-sum kernels walk their row loops (up to 12 k output positions), odd image
+	sizes included; training mode, against the oracle's forward and its autograd gradients."""
+	from vit_amd.layers import ConvEmbedding
+	torch.manual_seed(ci + co)
+	m = ConvEmbedding(ci, co, k, s, p)
+	with torch.no_grad():
+		m.norm.weight.uniform_(0.5, 1.5)
+		m.norm.bias.normal_(0, 0.3)
+	sd = {kk: v.detach().clone() for kk, v in m.state_dict().items()}
+	g = torch.Generator().manual_seed(1)
+	x0 = torch.randn(B, ci, hw, hw, generator=g)
+	leaf = {kk: v.double().requires_grad_(v.is_floating_point() and "running_" not in kk and "num_batches" not in kk) for kk, v in sd.items()}
+	xr = x0.double().requires_grad_(True)
+	y_ref = O.conv_embedding_fwd(xr, leaf, "", s, p, True)
+	gy0 = torch.randn(y_ref.shape, generator=g)
+	y_ref.backward(gy0.double())
+	m = m.to(gpu).train()
+	x = x0.to(gpu).to(dtype).requires_grad_(True)
+	y = m(x)
+	y.backward(gy0.to(gpu).to(dtype))
+	tol, gtol = (2e-4, 1e-3) if dtype == torch.float32 else (2e-2, 6e-2)
+	assert relerr(y, y_ref.detach()) < tol
+	assert relerr(x.grad, xr.grad) < gtol
+	for kk, pp in m.named_parameters():
+		assert relerr(pp.grad, leaf[kk].grad) < gtol, kk
