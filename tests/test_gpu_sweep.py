@@ -409,3 +409,34 @@ def test_conv_embedding_many_rows(gpu, dtype, ci, co, k, s, p, hw, B):
 	assert relerr(x.grad, xr.grad) < gtol
 	for kk, pp in m.named_parameters():
 		assert relerr(pp.grad, leaf[kk].grad) < gtol, kk
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dim,heads,hw,stride,B", [(64, 1, 8, 1, 200), (192, 3, 14, 2, 60), (128, 2, 7, 2, 90)])
+def test_conv_attention_many_rows(gpu, dtype, dim, heads, hw, stride, B):
+	"""ConvAttention (layers/attention.py:50-93 there) at batch sizes where the depthwise-convolution kernels (forward,
+	input gradient, LDS-reduced weight gradient) loop over positions and the attention kernels walk several (batch,
+	head) pairs per workgroup; odd maps with stride 2 included.  Against the oracle's forward and autograd gradients."""
+	from vit_amd.layers import ConvAttention
+	torch.manual_seed(dim + hw)
+	m = ConvAttention(dim, heads, kernel_size=3, qkv_stride=stride, padding=1, dropout=0.0)
+	sd = {kk: v.detach().clone() for kk, v in m.state_dict().items()}
+	g = torch.Generator().manual_seed(2)
+	x0 = torch.randn(B, hw * hw, dim, generator=g)
+	leaf = {kk: v.double().requires_grad_(True) for kk, v in sd.items()}
+	xr = x0.double().requires_grad_(True)
+	y_ref = O.conv_attention_fwd(xr, hw, hw, leaf, "", heads, stride, 1)
+	gy0 = torch.randn(y_ref.shape, generator=g)
+	y_ref.backward(gy0.double())
+	m = m.to(gpu)
+	x = x0.to(gpu).to(dtype).requires_grad_(True)
+	y = m(x, hw, hw)
+	y.backward(gy0.to(gpu).to(dtype))
+	tol, gtol = (1e-4, 1e-3) if dtype == torch.float32 else (2e-2, 6e-2)
+	assert relerr(y, y_ref.detach()) < tol
+	assert relerr(x.grad, xr.grad) < gtol
+	for kk, pp in m.named_parameters():
+		bound = gtol if not (dtype == torch.bfloat16 and kk.endswith("bias")) else 0.2  # token sums that largely cancel
+		if "k_proj.bias" in kk:
+			continue  # exactly zero in exact arithmetic (softmax is invariant to a shift of the scores): rounding noise only
+		assert relerr(pp.grad, leaf[kk].grad) < bound, kk
