@@ -440,3 +440,36 @@ def test_conv_attention_many_rows(gpu, dtype, dim, heads, hw, stride, B):
 		if "k_proj.bias" in kk:
 			continue  # exactly zero in exact arithmetic (softmax is invariant to a shift of the scores): rounding noise only
 		assert relerr(pp.grad, leaf[kk].grad) < bound, kk
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("ci,co,stride,expand,hw,B", [(32, 32, 1, 4, 28, 24), (64, 96, 2, 4, 28, 16), (24, 40, 2, 6, 15, 10)])
+def test_mbconv_many_rows(gpu, dtype, ci, co, stride, expand, hw, B):
+	"""MBConv (layers/conv.py:5-44 there) with SiLU at CoAtNet-like sizes (up to 19 k positions, 256 hidden channels, an
+	odd map with stride 2): training-mode BatchNorm, against the oracle's forward and its autograd gradients."""
+	from vit_amd.layers.conv import MBConv
+	torch.manual_seed(ci + co + hw)
+	m = MBConv(ci, co, stride=stride, expand_ratio=expand, activation="silu")
+	with torch.no_grad():
+		for mod in m.modules():
+			if isinstance(mod, torch.nn.BatchNorm2d):
+				mod.weight.uniform_(0.5, 1.5)
+				mod.bias.normal_(0, 0.3)
+	sd = {kk: v.detach().clone() for kk, v in m.state_dict().items()}
+	g = torch.Generator().manual_seed(3)
+	x0 = torch.randn(B, ci, hw, hw, generator=g)
+	leaf = {kk: (v.double().requires_grad_(True) if (v.is_floating_point() and "running_" not in kk) else v) for kk, v in sd.items()}
+	xr = x0.double().requires_grad_(True)
+	y_ref = O.mbconv_fwd(xr, leaf, "", stride, "silu", True)
+	gy0 = torch.randn(y_ref.shape, generator=g)
+	y_ref.backward(gy0.double())
+	m = m.to(gpu).train()
+	x = x0.to(gpu).to(dtype).requires_grad_(True)
+	y = m(x)
+	y.backward(gy0.to(gpu).to(dtype))
+	tol, gtol = (2e-4, 2e-3) if dtype == torch.float32 else (3e-2, 8e-2)
+	assert relerr(y, y_ref.detach()) < tol
+	assert relerr(x.grad, xr.grad) < gtol
+	for kk, pp in m.named_parameters():
+		bound = gtol if not (dtype == torch.bfloat16 and kk.endswith("bias")) else 0.2
+		assert relerr(pp.grad, leaf[kk].grad) < bound, kk
