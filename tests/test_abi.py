@@ -117,7 +117,7 @@ def test_feedforward_interface():
 
 @pytest.mark.skipif(not os.path.isdir("/root/reference/models"), reason="reference checkout not present (GPU box)")
 def test_reference_models_construct_on_top_of_these_layers():
-	"""The import switch of INTEGRATION.md: the reference's own models/vit.py and models/cvt.py build, unchanged, on
+	"""The import switch (alias this package's layers as `layers`): the reference's own models/vit.py and models/cvt.py build, unchanged, on
 	vit_amd.layers (run in a subprocess so that sys.modules of the test process stays clean)."""
 	import subprocess
 	import sys
