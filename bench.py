@@ -2,13 +2,17 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--config vit_b16|vit_tiny]
 
-For N > 1 it is launched as `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`
-(one rank per GPU, RCCL).  A step = forward + cross-entropy + backward + gradient all-reduce (N > 1) +
-fused AdamW on synthetic data already resident in HBM.  Rank 0 prints ONE JSON line.
+For N > 1 it runs one rank per GPU over RCCL: either started under a launcher that sets WORLD_SIZE / RANK / LOCAL_RANK
+(`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`), or started plainly, in which case it
+launches the N ranks itself as child processes (before anything in this process touches a GPU) and relays rank 0's
+line and the exit code.  A step = forward + cross-entropy + backward + gradient all-reduce (N > 1) + fused AdamW on
+synthetic data already resident in HBM.  Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -92,7 +96,42 @@ def cpu_baseline(c, seconds=20.0):
 		times.append(time.time() - t0)
 	med = sorted(times)[len(times) // 2]
 	return {"value": round(batch / med, 2), "unit": "images/sec", "cores": cores, "kind": "port",
-		"sample": f"{len(times)} timed fwd+loss+bwd iterations of the float32 CPU oracle at batch {batch} (same model config), median"}
+		"sample": f"{len(times)} timed fwd+loss+bwd iterations (no AdamW step) of the float32 CPU oracle at batch {batch} (same model config), "
+			"median; the GPU figure is fwd+loss+bwd+AdamW at the per-GPU batch of `config`"}
+
+
+def launch_ranks(n, argv):
+	"""Start `n` ranks of this script under torch.distributed.run as CHILD processes (this process has not touched a GPU
+	and never will), pass their stderr through, relay rank 0's JSON line and return the launcher's exit code."""
+	with socket.socket() as s:
+		s.bind(("127.0.0.1", 0))
+		port = s.getsockname()[1]
+	env = dict(os.environ)
+	env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+	env.setdefault("OMP_NUM_THREADS", "8")
+	cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+		"--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+	proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+	lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]
+	for ln in proc.stdout.splitlines():
+		if not ln.startswith("{"):
+			print(ln, file=sys.stderr)
+	if lines:
+		print(lines[-1], flush=True)
+	if proc.returncode == 0 and not lines:
+		print("bench.py: the ranks exited without a result line", file=sys.stderr)
+		return 1
+	return proc.returncode
+
+
+def launcher_selftest(world, rank):
+	"""What --launcher-selftest runs in each rank: no GPU, a gloo all-reduce, rank 0 prints a line (CPU test of launch_ranks)."""
+	dist.init_process_group("gloo")
+	t = torch.tensor([float(rank + 1)])
+	dist.all_reduce(t)
+	if rank == 0:
+		print(json.dumps({"selftest": True, "n_gpus": world, "sum": t.item()}), flush=True)
+	dist.destroy_process_group()
 
 
 def main():
@@ -106,13 +145,19 @@ def main():
 	ap.add_argument("--dropout", type=float, default=0.0, help="config.dropout (attention-probability, branch and feed-forward dropouts)")
 	ap.add_argument("--no-cpu-baseline", action="store_true")
 	ap.add_argument("--no-kernel-timing", action="store_true")
+	ap.add_argument("--lr", type=float, default=1e-4)
+	ap.add_argument("--launcher-selftest", action="store_true", help=argparse.SUPPRESS)
 	args = ap.parse_args()
 
+	if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+		raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
 	world = int(os.environ.get("WORLD_SIZE", "1"))
 	rank = int(os.environ.get("RANK", "0"))
 	local_rank = int(os.environ.get("LOCAL_RANK", "0"))
 	if world != args.gpus:
-		raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus}")
+		raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+	if args.launcher_selftest:
+		return launcher_selftest(world, rank)
 	torch.cuda.set_device(local_rank)
 	dev = torch.device("cuda", local_rank)
 	if world > 1:
@@ -131,7 +176,7 @@ def main():
 		model = CvT(make_cvt_config(args.dropout)).to(dev)
 	else:
 		model = ViT(make_config(c, args.dropout)).to(dev)
-	trainer = dp.Trainer(model, lr=1e-3, weight_decay=0.05)
+	trainer = dp.Trainer(model, lr=args.lr, weight_decay=0.05)
 	g = torch.Generator(device="cpu").manual_seed(1234 + rank)
 	x = torch.randn(batch, *c["chw"], generator=g).to(dev)
 	y = torch.randint(0, c["out_d"], (batch,), generator=g).to(dev)
@@ -162,8 +207,11 @@ def main():
 
 		def step():
 			return graphed(x, y)
+	first = None  # loss of the very first step (from the initial weights): with final_loss it shows the optimizer at work
 	for _ in range(args.warmup):
-		step()
+		l0 = step()
+		if first is None:
+			first = l0.detach().clone()
 	if not args.no_kernel_timing and rank == 0 and graphed is None:
 		ops.GEMM_PROFILE = []
 	barrier()
@@ -177,6 +225,7 @@ def main():
 		dist.all_reduce(t, op=dist.ReduceOp.MAX)
 	elapsed = t.item()
 	final_loss = loss.item()
+	first_loss = first.item() if first is not None else None
 	assert final_loss == final_loss, "loss is NaN"
 
 	if rank == 0 and is_cvt:
@@ -186,7 +235,7 @@ def main():
 			"scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
 			"config": {"workload": "cvt: CvTConfig defaults (64/192/384, depths 1/2/10, heads 1/3/6, silu, RMSNorm) at 32x32, 10 classes, fwd+CE+bwd+AdamW",
 				"global_batch": batch * world, "per_gpu_batch": batch, "parallelism": f"dp{world}", "hip_graph": bool(args.graph), "dropout": args.dropout},
-			"final_loss": round(final_loss, 4)}), flush=True)
+			"first_loss": None if first_loss is None else round(first_loss, 4), "final_loss": round(final_loss, 4), "lr": args.lr}), flush=True)
 	elif rank == 0:
 		value = batch * world * args.steps / elapsed
 		flops_img = train_flops_per_image(c)
@@ -200,7 +249,7 @@ def main():
 				"parallelism": f"dp{world}", "hip_graph": bool(args.graph), "dropout": args.dropout},
 			"train_gflop_per_image": round(flops_img / 1e9, 3),
 			"mfma_util_pct": round(100.0 * value * flops_img / (world * PEAK_BF16_TFLOPS * 1e12), 2),
-			"final_loss": round(final_loss, 4),
+			"first_loss": None if first_loss is None else round(first_loss, 4), "final_loss": round(final_loss, 4), "lr": args.lr,
 		}
 		if ops.GEMM_PROFILE:
 			prof, ops.GEMM_PROFILE = ops.GEMM_PROFILE, None
