@@ -267,6 +267,12 @@ int vitk_adamw(float* p, const float* g, float* m, float* v, const uint8_t* wd_m
  * (the reference's eager loop, train.py:42-59, re-reads the optimizer's host-side step each iteration). */
 int vitk_adamw_device_step(float* p, const float* g, float* m, float* v, const uint8_t* wd_mask, void* p_bf16, int64_t n,
 	float lr, float beta1, float beta2, float eps, float weight_decay, int64_t* step_state, float grad_scale, void* stream);
+/* The same with the hyper-parameters in DEVICE memory too, one set per parameter group of utils.py:102-121:
+ * hparams[8] = {lr, weight_decay of the group wd_mask selects, lr, weight_decay of the other group, beta1, beta2, eps, unused}.
+ * A learning-rate scheduler (main.py:113-131, schedulers.py:3-35) rewrites them between steps; a launch captured into a
+ * HIP graph then follows the schedule on replay. */
+int vitk_adamw_device_hparams(float* p, const float* g, float* m, float* v, const uint8_t* wd_mask, void* p_bf16, int64_t n,
+	const float* hparams, int64_t* step_state, float grad_scale, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * CvT pieces.

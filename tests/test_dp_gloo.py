@@ -122,3 +122,65 @@ def test_flat_model_layout():
 	assert covered[0][0] == 0 and covered[-1][1] == flat.numel
 	assert all(covered[i][1] == covered[i + 1][0] for i in range(len(covered) - 1))
 	assert dp.no_decay("blocks.0.attn_norm.weight") and dp.no_decay("mlp.bias") and not dp.no_decay("blocks.0.attn_layer_scale")
+
+
+def _shared_worker(rank, world, port, ret):
+	sys.path.insert(0, ROOT)
+	os.environ["MASTER_ADDR"] = "127.0.0.1"
+	os.environ["MASTER_PORT"] = str(port)
+	dist.init_process_group("gloo", rank=rank, world_size=world)
+	from vit_amd import dp
+
+	def build():
+		torch.manual_seed(0)
+		return nn.ModuleDict(dict(inp=nn.Linear(16, 32), shared=nn.Linear(32, 32), a=nn.Linear(32, 4), b=nn.Linear(32, 4)))
+
+	def fwd(m, x, branch):
+		h = torch.tanh(m["inp"](x))
+		h = torch.tanh(m["shared"](torch.tanh(m["shared"](h))))  # one module, two uses: its gradient is written twice
+		return m[branch](h)  # the other head stays unused in this rank's graph
+
+	model = build()
+	flat = dp.FlatModel(model, bucket_bytes=64)  # many buckets
+	sync = dp.GradSync(flat)
+	g = torch.Generator().manual_seed(7)
+	x_all, y_all = torch.randn(8, 16, generator=g), torch.randn(8, 4, generator=g)
+	xs, ys = x_all[rank::world], y_all[rank::world]
+	branch = "a" if rank == 0 else "b"  # the ranks' sets of unused parameters differ
+	grads, early = [], []
+	for step in range(3):
+		flat.zero_grad()
+		if step < 2:
+			((fwd(model, xs, branch) - ys) ** 2).sum().backward()
+		else:  # gradient accumulation: two micro-batches, only the second synchronises
+			with sync.no_sync():
+				((fwd(model, xs[:2], branch) - ys[:2]) ** 2).sum().backward()
+			((fwd(model, xs[2:], branch) - ys[2:]) ** 2).sum().backward()
+		early.append(len(sync.launched))
+		sync.finish()
+		grads.append(flat.grad.clone())
+	ref = build()
+	for r in range(world):
+		((fwd(ref, x_all[r::world], "a" if r == 0 else "b") - y_all[r::world]) ** 2).sum().backward()
+	ok = []
+	for name, p in ref.named_parameters():
+		i = flat.names.index(name)
+		o = flat.offsets[i]
+		want = p.grad if p.grad is not None else torch.zeros_like(p)
+		ok.append(all(torch.allclose(gr[o:o + p.numel()].view(p.shape), want, rtol=1e-5, atol=1e-6) for gr in grads))
+	ret[rank] = (all(ok), early, len(flat.buckets), sync.expected[flat.names.index("shared.weight")])
+	dist.destroy_process_group()
+
+
+def test_shared_module_microbatches_and_rank_dependent_unused_parameters():
+	world = 2
+	port = 29500 + (os.getpid() % 1000) + 11
+	mgr = mp.Manager()
+	ret = mgr.dict()
+	mp.spawn(_shared_worker, args=(world, port, ret), nprocs=world, join=True)
+	for rank in range(world):
+		ok, early, n_buckets, shared_expected = ret[rank]
+		assert ok, f"rank {rank}: reduced gradients differ from the global-batch gradients"
+		assert shared_expected == 1 or shared_expected == 2  # autograd accumulates both uses before its hook fires once
+		assert early[0] == 0, "the first backward only learns the write counts"
+		assert n_buckets >= 4

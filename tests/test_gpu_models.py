@@ -353,43 +353,81 @@ def test_mbconv_golden(gpu, case, mode, dtype):
 
 
 def test_graphed_training_step_matches_eager(gpu):
-	"""The captured-and-replayed training step (one HIP graph launch) follows the eager loop: same losses, same
-	parameters after the same number of optimizer steps on the same per-step batches."""
+	"""The captured-and-replayed training step (one HIP graph launch) follows the eager loop from the SAME start (the
+	warm-up steps that precede the capture are undone): same losses, same parameters after the same number of optimizer
+	steps on the same batches, and a stock learning-rate scheduler attached to the fused optimizer changes the update in
+	both (the kernel reads the hyper-parameters from device memory, so a replay sees the new rate)."""
 	from vit_amd import dp, ops
 	c = dict(d_model=64, n_head=1, n_block=2, n_patch=4, d_ff=128, out_d=10, chw=(3, 16, 16), activation="gelu", norm="layernorm",
 		use_layer_scale=False, dropout=0.0)
 	gen = torch.Generator().manual_seed(5)
-	xs = [torch.randn(8, 3, 16, 16, generator=gen).to(gpu) for _ in range(7)]
-	ys = [torch.randint(0, 10, (8,), generator=gen).to(gpu) for _ in range(7)]
+	xs = [torch.randn(8, 3, 16, 16, generator=gen).to(gpu) for _ in range(5)]
+	ys = [torch.randint(0, 10, (8,), generator=gen).to(gpu) for _ in range(5)]
 
-	def run(graphed):
+	def run(graphed, scheduled=True):
+		ops.clear_grad_sinks()
 		torch.manual_seed(0)
 		model = make_vit(c, gpu)
 		trainer = dp.Trainer(model, lr=1e-2, weight_decay=0.05)
+		sched = torch.optim.lr_scheduler.StepLR(trainer.opt, step_size=2, gamma=0.1) if scheduled else None
 
 		def loss_fn(x, y):
 			with torch.autocast("cuda", dtype=torch.bfloat16):
 				return ops.cross_entropy(model(x), y)
-		losses = []
-		if graphed:
-			g = dp.GraphedStep(trainer, loss_fn, [xs[0], ys[0]], warmup=3)  # 3 eager steps on batch 0
-			for i in range(3, 7):
+		losses, lrs = [], []
+		g = dp.GraphedStep(trainer, loss_fn, [xs[0], ys[0]], warmup=3) if graphed else None
+		assert trainer.opt.step_count == 0 and int(trainer.opt.step_state[0]) == 0
+		for i in range(5):
+			lrs.append(trainer.opt.param_groups[0]["lr"])
+			if graphed:
 				losses.append(float(g(xs[i], ys[i])))
-		else:
-			for i in [0, 0, 0, 3, 4, 5, 6]:
+			else:
 				trainer.zero_grad()
 				loss = loss_fn(xs[i], ys[i])
 				loss.backward()
 				trainer.step()
 				losses.append(float(loss.detach()))
-			losses = losses[3:]
-		assert trainer.opt.step_count == 7 and int(trainer.opt.step_state[0]) == 7
-		return losses, trainer.flat.param.clone()
+			if sched is not None:
+				sched.step()
+		assert trainer.opt.step_count == 5 and int(trainer.opt.step_state[0]) == 5
+		out = losses, trainer.flat.param.clone(), lrs
+		trainer.close()
+		return out
 
-	le, pe = run(False)
-	lg, pg = run(True)
+	le, pe, lrs = run(False)
+	lg, pg, lrs_g = run(True)
+	assert lrs == lrs_g and lrs[0] == 1e-2 and abs(lrs[-1] - 1e-4) < 1e-12
+	assert abs(le[0] - lg[0]) < 1e-3 * abs(le[0])  # both start from the initial weights
 	assert max(abs(a - b) for a, b in zip(le, lg)) < 2e-2 * max(abs(a) for a in le)  # bf16 step, atomics order
 	assert relerr(pg, pe.cpu().double()) < 2e-2
+	_, p_const, _ = run(True, scheduled=False)
+	assert relerr(p_const, pe.cpu().double()) > 10 * relerr(pg, pe.cpu().double())  # the schedule did change the replayed updates
+
+
+def test_stale_weight_copies_are_refreshed_or_refused(gpu):
+	"""A parameter written in place behind the fused optimizer's back (load_state_dict, an initialiser) moves its version
+	counter: the next forward re-derives the bfloat16 / transposed copies instead of computing with stale weights."""
+	from vit_amd import dp, ops
+	c = dict(d_model=64, n_head=1, n_block=1, n_patch=4, d_ff=128, out_d=10, chw=(3, 16, 16), activation="gelu", norm="layernorm",
+		use_layer_scale=False, dropout=0.0)
+	ops.clear_grad_sinks()
+	torch.manual_seed(0)
+	model = make_vit(c, gpu)
+	trainer = dp.Trainer(model)
+	x = torch.randn(4, 3, 16, 16, generator=torch.Generator().manual_seed(1)).to(gpu)
+	with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+		y0 = model(x).float()
+		sd = {k: v.clone() for k, v in model.state_dict().items()}
+		for k in sd:
+			if k.endswith("fc_in.weight") or k.endswith("mlp.weight"):
+				sd[k] = sd[k] * 3.0
+		model.load_state_dict(sd)  # NOT checkpoint.load_model_state_dict: nobody tells the optimizer
+		y1 = model(x).float()
+		w = dict(model.named_parameters())["mlp.weight"]
+		assert torch.equal(ops.weight_as(w, torch.bfloat16), w.detach().to(torch.bfloat16))
+	assert relerr(y1, y0.cpu().double()) > 0.1
+	trainer.close()
+	assert ops._shadows == {} or all(r[0]() is not w for r in ops._shadows.values())
 
 
 @pytest.mark.parametrize("cfg", ["ln_gelu", "rms_swiglu_ls"])

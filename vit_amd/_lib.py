@@ -79,6 +79,7 @@ SIGNATURES = {
 	"vitk_ce_kd_loss": [P, P, P, P, P, I64, I64, FL, FL, FL, I, P],
 	"vitk_adamw": [P, P, P, P, P, P, I64, FL, FL, FL, FL, FL, I64, FL, P],
 	"vitk_adamw_device_step": [P, P, P, P, P, P, I64, FL, FL, FL, FL, FL, P, FL, P],
+	"vitk_adamw_device_hparams": [P, P, P, P, P, P, I64, P, P, FL, P],
 	"vitk_dwconv_fwd": [P, P, P, I64, I64, I64, I64, I64, I64, I64, I, P],
 	"vitk_dwconv_bwd": [P, P, P, P, P, I64, I64, I64, I64, I64, I64, I64, I, P],
 	"vitk_im2col": [P, P, I64, I64, I64, I64, I64, I64, I64, I, I, P],

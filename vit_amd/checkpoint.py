@@ -41,6 +41,13 @@ def optimizer_state_dict(opt, decay_filter=no_decay):
 		dict(common, weight_decay=opt.weight_decay, params=list(range(len(dec)))),
 		dict(common, weight_decay=0.0, params=list(range(len(dec), len(dec) + len(nod)))),
 	]
+	# per-group learning rates and what schedulers keep in the groups (initial_lr ...)
+	live = {0: getattr(opt, "_decay_group", None), 1: getattr(opt, "_nodecay_group", None)}
+	for k, gi in live.items():
+		if gi is not None:
+			for key, val in opt.param_groups[gi].items():
+				if key not in ("params", "betas"):
+					groups[k][key] = val
 	return {"state": state, "param_groups": groups}
 
 
@@ -73,6 +80,12 @@ def load_optimizer_state_dict(opt, sd, decay_filter=no_decay):
 	opt.set_step(steps.pop() if steps else 0)
 	g0 = groups[0]
 	opt.lr, opt.betas, opt.eps, opt.weight_decay = g0["lr"], tuple(g0["betas"]), g0["eps"], g0["weight_decay"]
+	live = {0: getattr(opt, "_decay_group", None), 1: getattr(opt, "_nodecay_group", None)}
+	for k, gi in live.items():
+		if gi is not None:
+			for key in ("lr", "initial_lr"):
+				if key in groups[k]:
+					opt.param_groups[gi][key] = groups[k][key]
 
 
 def load_model_state_dict(trainer_or_none, module, sd, strict=True):

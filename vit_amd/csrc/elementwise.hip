@@ -333,7 +333,14 @@ __global__ __launch_bounds__(256) void ce_kd_kernel(const T* __restrict__ logits
 // ---- fused AdamW -----------------------------------------------------------------------------------
 // step_state (nullable): two int64 words in device memory, [0] = step count, [1] = the step's two bias-correction factors
 // as floats (computed in double, like the host path), so that a captured (graph-replayed) launch sees a new step each time.
-__global__ void adamw_advance_kernel(int64_t* step_state, float b1, float b2) {
+// hp (nullable): hyper-parameters in device memory, {lr, weight_decay} of the decayed group, {lr, weight_decay} of the other
+// group, beta1, beta2, eps (8 floats with one pad); they override the by-value arguments, so a captured launch follows a
+// learning-rate schedule.
+__global__ void adamw_advance_kernel(int64_t* step_state, float b1, float b2, const float* hp) {
+	if (hp != nullptr) {
+		b1 = hp[4];
+		b2 = hp[5];
+	}
 	const int64_t st = step_state[0] + 1;
 	step_state[0] = st;
 	float* corr = reinterpret_cast<float*>(step_state + 1);  // [1]: the two bias-correction factors of this step
@@ -343,17 +350,29 @@ __global__ void adamw_advance_kernel(int64_t* step_state, float b1, float b2) {
 
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
 	const uint8_t* __restrict__ wd_mask, bf16_t* __restrict__ p16, int64_t n, float lr, float b1, float b2, float eps, float wd, float inv_bc1,
-	float inv_sqrt_bc2, float gscale, const int64_t* __restrict__ step_state) {
+	float inv_sqrt_bc2, float gscale, const int64_t* __restrict__ step_state, const float* __restrict__ hp) {
 	if (step_state != nullptr) {
 		const float* corr = reinterpret_cast<const float*>(step_state + 1);
 		inv_bc1 = corr[0];
 		inv_sqrt_bc2 = corr[1];
 	}
+	float lr1 = lr, wd1 = 0.f;  // the group wd_mask leaves out
+	if (hp != nullptr) {
+		lr = hp[0];
+		wd = hp[1];
+		lr1 = hp[2];
+		wd1 = hp[3];
+		b1 = hp[4];
+		b2 = hp[5];
+		eps = hp[6];
+	}
+	const float lr0 = lr, wd0 = wd;
 	for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
 		const float gr = g[i] * gscale;
 		float pv = p[i];
 		const bool decay = wd_mask ? wd_mask[i] != 0 : true;
-		if (decay) pv *= 1.f - lr * wd;
+		lr = decay ? lr0 : lr1;
+		pv *= 1.f - lr * (decay ? wd0 : wd1);
 		const float mv = b1 * m[i] + (1.f - b1) * gr;
 		const float vv = b2 * v[i] + (1.f - b2) * gr * gr;
 		const float denom = sqrtf(vv) * inv_sqrt_bc2 + eps;
@@ -648,7 +667,7 @@ extern "C" int vitk_adamw(float* p, const float* g, float* m, float* v, const ui
 	const double bc1 = 1.0 - pow((double)beta1, (double)step);
 	const double bc2 = 1.0 - pow((double)beta2, (double)step);
 	hipLaunchKernelGGL(adamw_kernel, dim3(vitk_stream_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, wd_mask, (bf16_t*)p_bf16, n, lr, beta1, beta2, eps,
-		weight_decay, (float)(1.0 / bc1), (float)(1.0 / sqrt(bc2)), grad_scale, (const int64_t*)nullptr);
+		weight_decay, (float)(1.0 / bc1), (float)(1.0 / sqrt(bc2)), grad_scale, (const int64_t*)nullptr, (const float*)nullptr);
 	VITK_CHECK_LAUNCH();
 	return VITK_OK;
 }
@@ -657,10 +676,23 @@ extern "C" int vitk_adamw_device_step(float* p, const float* g, float* m, float*
 	float beta2, float eps, float weight_decay, int64_t* step_state, float grad_scale, void* stream) {
 	VITK_REQUIRE(p && g && m && v && step_state, VITK_ERR_NULL);
 	VITK_REQUIRE(n > 0, VITK_ERR_SHAPE);
-	hipLaunchKernelGGL(adamw_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step_state, beta1, beta2);
+	hipLaunchKernelGGL(adamw_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step_state, beta1, beta2, (const float*)nullptr);
 	VITK_CHECK_LAUNCH();
 	hipLaunchKernelGGL(adamw_kernel, dim3(vitk_stream_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, wd_mask, (bf16_t*)p_bf16, n, lr, beta1, beta2, eps,
-		weight_decay, 1.f, 1.f, grad_scale, (const int64_t*)step_state);
+		weight_decay, 1.f, 1.f, grad_scale, (const int64_t*)step_state, (const float*)nullptr);
+	VITK_CHECK_LAUNCH();
+	return VITK_OK;
+}
+
+extern "C" int vitk_adamw_device_hparams(float* p, const float* g, float* m, float* v, const uint8_t* wd_mask, void* p_bf16, int64_t n, const float* hparams,
+	int64_t* step_state, float grad_scale, void* stream) {
+	VITK_REQUIRE(p && g && m && v && step_state && hparams, VITK_ERR_NULL);
+	VITK_REQUIRE(n > 0, VITK_ERR_SHAPE);
+	VITK_REQUIRE(vitk_aligned(hparams, 4), VITK_ERR_ALIGN);
+	hipLaunchKernelGGL(adamw_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step_state, 0.f, 0.f, hparams);
+	VITK_CHECK_LAUNCH();
+	hipLaunchKernelGGL(adamw_kernel, dim3(vitk_stream_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, wd_mask, (bf16_t*)p_bf16, n, 0.f, 0.f, 0.f, 0.f, 0.f,
+		1.f, 1.f, grad_scale, (const int64_t*)step_state, hparams);
 	VITK_CHECK_LAUNCH();
 	return VITK_OK;
 }

@@ -89,13 +89,22 @@ def broadcast_replica(flat, src=0, process_group=None):
 
 
 class GradSync:
-	"""Bucketed all-reduce(sum) of FlatModel.grad, launched from autograd hooks during backward."""
+	"""Bucketed all-reduce(sum) of FlatModel.grad, launched from autograd hooks during backward.
+
+	A gradient may be written several times per step (a module called twice, tied weights, several sink-aware backward
+	functions on one parameter), so a parameter counts as final only after as many reports as its FIRST synchronised
+	backward produced; that first backward launches nothing early (all buckets go out in finish()).  Buckets are always
+	launched in index order (the order their gradients become final in a backward pass), each as soon as it and all its
+	predecessors are complete, so every rank issues the same sequence of collectives even when the ranks' sets of
+	unused parameters differ.  Inside no_sync() backward passes only accumulate (micro-batches); the reports of the
+	next backward outside it are counted."""
 
 	def __init__(self, flat, process_group=None):
 		self.flat = flat
 		self.group = process_group
 		self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
-		self.pending = [0] * len(flat.buckets)
+		self.expected = None  # reports per parameter in one backward, learnt from the first synchronised one
+		self.enabled = True
 		self.works = []
 		self.launched = []
 		self.hooks = [None] * len(flat.params)
@@ -106,25 +115,52 @@ class GradSync:
 		self.reset()
 
 	def reset(self):
-		self.pending = [len(idxs) for _, _, idxs in self.flat.buckets]
+		self.counts = [0] * len(self.flat.params)
 		self.works = []
 		self.launched = []
 		self.arrivals = []  # parameter indices in the order their gradients became final (diagnostics / tests)
-		self.arrived = set()
+		self.next_bucket = 0
+		self.late = None
+		if self.expected is not None:
+			self.pending = [sum(1 for i in idxs if self.expected[i] > 0) for _, _, idxs in self.flat.buckets]
+		else:
+			self.pending = [len(idxs) for _, _, idxs in self.flat.buckets]
+
+	class _NoSync:
+		def __init__(self, sync):
+			self.sync = sync
+
+		def __enter__(self):
+			self.prev, self.sync.enabled = self.sync.enabled, False
+
+		def __exit__(self, *exc):
+			self.sync.enabled = self.prev
+
+	def no_sync(self):
+		"""Context manager: backward passes inside it accumulate into the flat gradient without any collective (gradient
+		accumulation over micro-batches); run the last micro-batch's backward outside it."""
+		return GradSync._NoSync(self)
 
 	def _make_hook(self, i):
 		def hook(_param):
-			# A parameter is counted once per step: one whose gradient went to its sink reports from inside the backward
-			# function, and autograd's post-accumulate hook may fire for it as well afterwards.
-			if i in self.arrived:
+			if not self.enabled:
 				return
-			self.arrived.add(i)
+			self.counts[i] += 1
+			if self.expected is None:
+				return  # first synchronised backward: learn the counts, launch everything in finish()
 			b = self.flat.bucket_of[i]
-			self.arrivals.append(i)
-			self.pending[b] -= 1
-			if self.pending[b] == 0:
-				self._launch(b)
+			if self.counts[i] == self.expected[i]:
+				self.arrivals.append(i)
+				self.pending[b] -= 1
+				self._launch_ready()
+			elif self.counts[i] > self.expected[i] and b < self.next_bucket:
+				self.late = i  # written after its bucket went out: the replicas would diverge; finish() raises
 		return hook
+
+	def _launch_ready(self):
+		while self.next_bucket < len(self.flat.buckets) and self.pending[self.next_bucket] <= 0:
+			self._launch(self.next_bucket)
+			self.next_bucket += 1
 
 	def _launch(self, b):
 		start, end, _ = self.flat.buckets[b]
@@ -132,35 +168,60 @@ class GradSync:
 		self.works.append(dist.all_reduce(self.flat.grad[start:end], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
 	def finish(self):
-		"""Wait for the collectives of this step (launching any bucket whose hooks did not all fire, e.g. unused
-		parameters).  After this the flat gradient holds the SUM over ranks; the optimizer applies 1/world."""
+		"""Wait for the collectives of this step (launching, in order, every bucket that has not gone out: the first
+		step's, and those holding parameters that received fewer gradient writes than expected, e.g. unused ones).
+		After this the flat gradient holds the SUM over ranks; the optimizer applies 1/world."""
 		if self.world > 1:
-			for b, n in enumerate(self.pending):
-				if n > 0:
-					self._launch(b)
+			if self.late is not None:
+				name = self.flat.names[self.late]
+				self.reset()
+				raise RuntimeError(f"gradient of {name} was written after its bucket had been all-reduced (the autograd graph changed between steps); "
+					"build a new GradSync / Trainer for the new graph")
+			while self.next_bucket < len(self.flat.buckets):
+				self._launch(self.next_bucket)
+				self.next_bucket += 1
 			for w in self.works:
 				w.wait()
+			if self.expected is None:
+				self.expected = list(self.counts)
 		self.reset()
 
 
-class FlatAdamW:
+class FlatAdamW(torch.optim.Optimizer):
 	"""torch.optim.AdamW semantics (main.py:100 there) as ONE kernel over the flat buffers, which also writes the
-	bfloat16 copy of the parameters that the next forward's GEMMs read."""
+	bfloat16 copy of the parameters that the next forward's GEMMs read.
+
+	It is a torch.optim.Optimizer with the reference's two parameter groups (utils.py:102-121 there: decayed parameters,
+	then the undecayed ones), so the stock learning-rate schedulers and the reference's warm-up wrapper
+	(schedulers.py:3-35, main.py:113-131) attach to it and drive `param_groups[i]["lr"]`.  The kernel reads the
+	hyper-parameters of both groups from a small device buffer that step() refreshes from `param_groups` whenever they
+	changed, so a step captured into a HIP graph follows the schedule as well (GraphedStep refreshes the buffer before
+	each replay)."""
 
 	def __init__(self, flat, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, decay_filter=no_decay, bf16_shadow=True):
 		self.flat = flat
-		self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
+		dec = [p for n, p in zip(flat.names, flat.params) if not decay_filter(n)]
+		nod = [p for n, p in zip(flat.names, flat.params) if decay_filter(n)]
+		groups = [{"params": dec, "weight_decay": weight_decay}, {"params": nod, "weight_decay": 0.0}]
+		groups = [g for g in groups if g["params"]] or groups[:1]
+		super().__init__(groups, dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay))
+		self._decay_group = 0 if dec else None
+		self._nodecay_group = (1 if dec else 0) if nod else None
 		dev = flat.param.device
 		self.m = torch.zeros_like(flat.param)
 		self.v = torch.zeros_like(flat.param)
 		self.step_count = 0
 		self.step_state = torch.zeros(2, dtype=torch.int64, device=dev)
+		self.hparams = torch.zeros(8, dtype=torch.float32, device=dev)
+		self._hparams_host = torch.zeros(8, dtype=torch.float32).pin_memory() if dev.type == "cuda" else torch.zeros(8)
+		self._hparams_sent = None
 		mask = torch.ones(flat.numel, dtype=torch.uint8, device="cpu")
 		for n, p, o in zip(flat.names, flat.params, flat.offsets):
 			if decay_filter(n):
 				mask[o:o + p.numel()] = 0
 		self.wd_mask = mask.to(dev)
 		self.shadow = None
+		self._registered = []
 		if bf16_shadow:
 			self.shadow = torch.empty(flat.numel, dtype=torch.bfloat16, device=dev)
 			L.check(L.load().vitk_cast(L.ptr(flat.param), L.ptr(self.shadow), flat.numel, L.F32, L.BF16, L.stream()))
@@ -170,7 +231,8 @@ class FlatAdamW:
 			for p, o in zip(flat.params, flat.offsets):
 				if p.dim() >= 2:
 					sh = self.shadow[o:o + p.numel()].view(p.shape)
-					ops.register_shadow(p, sh)
+					ops.register_shadow(p, sh, self.refresh_copies)
+					self._registered.append((p, sh))
 					if p.dim() == 2:
 						rows, cols = p.shape
 						sht = self.shadow_t[o:o + p.numel()].view(cols, rows)
@@ -182,6 +244,42 @@ class FlatAdamW:
 			self.t_items = torch.tensor(items, dtype=torch.int64).reshape(-1, 4).to(dev)  # vitk_transpose_item: 2 pointers + 2 int64
 			self.t_tiles = torch.tensor(tiles, dtype=torch.int32).reshape(-1, 4).to(dev)
 			self._refresh_transposed()
+		self.sync_hparams()
+
+	# the first group's hyper-parameters under the names the fused optimizer had before it grew parameter groups
+	def _g0(self):
+		return self.param_groups[0]
+
+	lr = property(lambda self: self._g0()["lr"], lambda self, v: [g.__setitem__("lr", v) for g in self.param_groups] and None)
+	betas = property(lambda self: self._g0()["betas"], lambda self, v: [g.__setitem__("betas", tuple(v)) for g in self.param_groups] and None)
+	eps = property(lambda self: self._g0()["eps"], lambda self, v: [g.__setitem__("eps", v) for g in self.param_groups] and None)
+
+	@property
+	def weight_decay(self):
+		return self.param_groups[self._decay_group]["weight_decay"] if self._decay_group is not None else 0.0
+
+	@weight_decay.setter
+	def weight_decay(self, v):
+		if self._decay_group is not None:
+			self.param_groups[self._decay_group]["weight_decay"] = v
+
+	def _hparam_values(self):
+		g0 = self.param_groups[self._decay_group] if self._decay_group is not None else None
+		g1 = self.param_groups[self._nodecay_group] if self._nodecay_group is not None else None
+		ref = g0 or g1
+		b1, b2 = ref["betas"]
+		f = lambda g, k: float(g[k]) if g is not None else 0.0
+		return (f(g0, "lr"), f(g0, "weight_decay"), f(g1, "lr"), f(g1, "weight_decay"), float(b1), float(b2), float(ref["eps"]), 0.0)
+
+	def sync_hparams(self):
+		"""Copy the hyper-parameters of `param_groups` to the device buffer the kernel reads, if they changed (never
+		during stream capture: a captured step picks them up from the buffer)."""
+		vals = self._hparam_values()
+		if vals == self._hparams_sent or (self.hparams.is_cuda and torch.cuda.is_current_stream_capturing()):
+			return
+		self._hparams_host.copy_(torch.tensor(vals, dtype=torch.float32))
+		self.hparams.copy_(self._hparams_host, non_blocking=False)
+		self._hparams_sent = vals
 
 	def _refresh_transposed(self):
 		if self.shadow is not None and self.t_tiles.shape[0] > 0:
@@ -189,25 +287,47 @@ class FlatAdamW:
 
 	def refresh_copies(self):
 		"""Re-derive the bfloat16 and transposed copies after the float32 parameters were written from outside
-		(load_state_dict, a broadcast)."""
+		(load_state_dict, a broadcast).  weight_as() calls this by itself when a parameter's version counter moved."""
 		if self.shadow is not None:
 			L.check(L.load().vitk_cast(L.ptr(self.flat.param), L.ptr(self.shadow), self.flat.numel, L.F32, L.BF16, L.stream()))
 			self._refresh_transposed()
+			for p, _ in self._registered:
+				ops.shadow_in_sync(p)
 		ops.invalidate_casts()
 		ops.weights_changed()
+
+	def close(self):
+		"""Withdraw the copies registered with ops (they would otherwise outlive this optimizer with stale contents)."""
+		for p, sh in self._registered:
+			ops.unregister_shadow(p)
+			ops.unregister_transposed(sh)
+		self._registered = []
 
 	def set_step(self, n):
 		"""Set the number of steps taken so far (resuming from a checkpoint)."""
 		self.step_count = int(n)
 		self.step_state.fill_(int(n))
 
-	def step(self, grad_scale=1.0):
+	def zero_grad(self, set_to_none=False):
+		self.flat.zero_grad()  # the gradients stay views of the flat buffer
+
+	def state_dict(self):
+		from . import checkpoint
+		return checkpoint.optimizer_state_dict(self)
+
+	def load_state_dict(self, sd):
+		from . import checkpoint
+		checkpoint.load_optimizer_state_dict(self, sd)
+
+	def step(self, closure=None, grad_scale=1.0):
 		# the step count that the bias corrections use lives in device memory (self.step_state) and is advanced by the
 		# launch itself, so the same launch can be replayed from a captured HIP graph; step_count mirrors it on the host
+		assert closure is None, "the fused step takes no closure"
 		self.step_count += 1
+		self.sync_hparams()
 		f = self.flat
-		L.check(L.load().vitk_adamw_device_step(L.ptr(f.param), L.ptr(f.grad), L.ptr(self.m), L.ptr(self.v), L.ptr(self.wd_mask), L.ptr(self.shadow), f.numel,
-			self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay, L.ptr(self.step_state), grad_scale, L.stream()))
+		L.check(L.load().vitk_adamw_device_hparams(L.ptr(f.param), L.ptr(f.grad), L.ptr(self.m), L.ptr(self.v), L.ptr(self.wd_mask), L.ptr(self.shadow), f.numel,
+			L.ptr(self.hparams), L.ptr(self.step_state), grad_scale, L.stream()))
 		if self.shadow is None:
 			ops.invalidate_casts()  # the kernel writes the parameters without bumping their version counters
 		self._refresh_transposed()
@@ -230,9 +350,19 @@ class Trainer:
 	def zero_grad(self):
 		self.flat.zero_grad()
 
+	def no_sync(self):
+		"""Gradient accumulation: `with trainer.no_sync(): loss.backward()` for all micro-batches but the last."""
+		return self.sync.no_sync()
+
 	def step(self):
 		self.sync.finish()
-		self.opt.step(1.0 / self.sync.world)
+		self.opt.step(grad_scale=1.0 / self.sync.world)
+
+	def close(self):
+		"""Withdraw everything this trainer registered with ops (bf16 / transposed weight copies, gradient sinks)."""
+		self.opt.close()
+		for p in self.flat.params:
+			ops.unregister_grad_sink(p)
 
 
 class GraphedStep:
@@ -241,39 +371,56 @@ class GraphedStep:
 	(ViT-Tiny on 32x32: ~1 ms of GPU work per step behind ~8 ms of launch overhead) is bound by.  The reference's loop
 	(train.py:42-59) is eager and synchronises twice per step; this is the launch-free form of the same step.
 
-	`loss_fn(*inputs)` must return the scalar loss and may only depend on its tensor arguments (their shapes and dtypes
-	are fixed at capture; new values are copied into the captured input buffers).  Single process only (the gradient
-	all-reduce hooks are not captured).  Counter-based dropout would replay the captured seed: use dropout 0 or
-	accept a fixed mask.  The returned loss tensor is overwritten by the next call."""
+	`loss_fn(*inputs)` returns the scalar loss, or (loss, logits), and may only depend on its tensor arguments (their
+	shapes and dtypes are fixed at capture; new values are copied into the captured input buffers).  Single process only
+	(the gradient all-reduce hooks are not captured).  The warm-up steps that precede the capture (lazy one-time set-up
+	must not happen while capturing) run on the example inputs and are then UNDONE: parameters, optimizer moments, step
+	count, module buffers (BatchNorm statistics) and the dropout seed counter are restored, so the first replay is the
+	first training step and the trajectory equals the eager one.  Learning rate and the other hyper-parameters are
+	re-read from the optimizer's param_groups before every replay.  Dropout seeds are host-side values fixed at capture,
+	so a captured step with dropout > 0 replays one mask: use dropout 0 or accept that.  The returned tensors are
+	overwritten by the next call."""
 
 	def __init__(self, trainer, loss_fn, example_inputs, warmup=3):
 		assert trainer.sync.world == 1, "graph capture of the step is single-process"
 		assert ops.GEMM_PROFILE is None, "no per-launch event timing inside a captured step"
 		self.trainer, self.loss_fn = trainer, loss_fn
 		self.inputs = [t.clone() for t in example_inputs]
+		opt, flat = trainer.opt, trainer.flat
+		saved = [t.clone() for t in (flat.param, opt.m, opt.v, opt.step_state)]
+		bufs = [(b, b.clone()) for b in flat.module.buffers()]
+		saved_steps, saved_seed = opt.step_count, ops.seed_counter()
 		side = torch.cuda.Stream()
 		side.wait_stream(torch.cuda.current_stream())
-		with torch.cuda.stream(side):  # warm-up off the default stream: lazy one-time setup must not happen during capture
+		with torch.cuda.stream(side):  # warm-up off the default stream
 			for _ in range(warmup):
 				self._eager()
 		torch.cuda.current_stream().wait_stream(side)
 		self.graph = torch.cuda.CUDAGraph()
 		with torch.cuda.graph(self.graph):
-			self.loss = self._eager()
-		self.steps_in_capture = warmup + 1  # optimizer steps already taken (the capture itself executes nothing)
-		trainer.opt.step_count -= 1  # the captured step did not run; the device-side counter was not advanced either
+			out = self._eager()
+		self.loss, self.logits = out if isinstance(out, tuple) else (out, None)
+		for dst, src in zip((flat.param, opt.m, opt.v, opt.step_state), saved):
+			dst.copy_(src)
+		for b, src in bufs:
+			b.copy_(src)
+		opt.step_count = saved_steps
+		ops.set_seed_counter(saved_seed)
+		opt.refresh_copies()
 
 	def _eager(self):
 		self.trainer.zero_grad()
-		loss = self.loss_fn(*self.inputs)
+		out = self.loss_fn(*self.inputs)
+		loss, logits = out if isinstance(out, tuple) else (out, None)
 		loss.backward()
 		self.trainer.step()
-		return loss.detach()
+		return loss.detach() if logits is None else (loss.detach(), logits.detach())
 
 	def __call__(self, *inputs):
 		for dst, src in zip(self.inputs, inputs):
 			if dst.data_ptr() != src.data_ptr():
 				dst.copy_(src, non_blocking=True)
+		self.trainer.opt.sync_hparams()
 		self.graph.replay()
 		self.trainer.opt.step_count += 1
-		return self.loss
+		return self.loss if self.logits is None else (self.loss, self.logits)

@@ -44,15 +44,29 @@ def cast(t, dtype):
 _cast_cache = {}  # id(param) -> (weakref(param), key, cast copy)
 
 
-_shadows = {}  # id(param) -> (weakref(param), bf16 copy kept in sync by the optimizer kernel)
+_shadows = {}  # id(param) -> [weakref(param), bf16 copy kept in sync by the optimizer kernel, param._version it matches, refresh callback]
 
 
-def register_shadow(param, shadow_bf16):
+def register_shadow(param, shadow_bf16, refresh=None):
 	"""Declare `shadow_bf16` to be a bfloat16 copy of `param` that its owner keeps up to date (the fused AdamW
-	kernel rewrites it with every step); weight_as() then returns it without casting."""
+	kernel rewrites it with every step, without touching the parameter's version counter); weight_as() then returns it
+	without casting.  The parameter's version is recorded: when anything else writes the parameter in place
+	(load_state_dict, an initialiser, another optimizer) the version moves, and weight_as() calls `refresh()` — which must
+	re-derive the copies and call shadow_in_sync() — or raises if there is none, instead of computing with stale weights."""
 	assert shadow_bf16.dtype == torch.bfloat16 and shadow_bf16.shape == param.shape and shadow_bf16.is_contiguous()
 	pid = id(param)
-	_shadows[pid] = (weakref.ref(param, lambda _r, pid=pid: _shadows.pop(pid, None)), shadow_bf16)
+	_shadows[pid] = [weakref.ref(param, lambda _r, pid=pid: _shadows.pop(pid, None)), shadow_bf16, param._version, refresh]
+
+
+def shadow_in_sync(param):
+	"""The owner of `param`'s registered copy has just rewritten it from the parameter's current value."""
+	rec = _shadows.get(id(param))
+	if rec is not None and rec[0]() is param:
+		rec[2] = param._version
+
+
+def unregister_shadow(param):
+	_shadows.pop(id(param), None)
 
 
 def invalidate_casts():
@@ -69,6 +83,11 @@ def weight_as(w, dtype):
 	if dtype == torch.bfloat16:
 		sh = _shadows.get(id(w))
 		if sh is not None and sh[0]() is w:
+			if sh[2] != w._version:
+				if sh[3] is None:
+					raise RuntimeError("a parameter with a registered bfloat16 copy was modified in place by something other than its optimizer; "
+						"call the optimizer's refresh_copies() after writing parameters")
+				sh[3]()
 			return sh[1]
 	key = (w._version, dtype, w.data_ptr())
 	hit = _cast_cache.get(id(w))
@@ -146,6 +165,14 @@ def register_grad_sink(param, buffer, on_written=None):
 
 def clear_grad_sinks():
 	_grad_sinks.clear()
+
+
+def unregister_grad_sink(param):
+	_grad_sinks.pop(id(param), None)
+
+
+def unregister_transposed(wc):
+	_wt_kept.pop(id(wc), None)
 
 
 def _sink(p):
@@ -911,6 +938,14 @@ def next_dropout_seed():
 	a per-call counter; no device synchronisation."""
 	_dropout_calls[0] += 1
 	return (torch.initial_seed() * 0x9E3779B1 + _dropout_calls[0] * 0x85EBCA77) & 0xFFFFFFFFFFFFFFFF
+
+
+def seed_counter():
+	return _dropout_calls[0]
+
+
+def set_seed_counter(n):
+	_dropout_calls[0] = int(n)
 
 
 def dropout(x, p):

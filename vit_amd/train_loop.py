@@ -7,7 +7,8 @@ The returned (avg_loss, accuracy) are defined as there: sum of per-step losses /
 In the training state the step is zero_grad -> forward -> loss -> backward -> optimizer step; `trainer` may be a
 vit_amd.dp.Trainer (flat buffers, fused AdamW, RCCL gradient sync) or any object with zero_grad() and step()
 (torch.optim optimizers qualify).  A captured step (vit_amd.dp.GraphedStep) can be passed as `graphed_step`; it then
-replaces forward/backward/update and must return the loss tensor.
+replaces forward/backward/update and returns the loss tensor, or (loss, logits) when its loss_fn returns both; without
+logits the epoch's accuracy is reported as NaN (unknown), not 0.
 """
 import torch
 
@@ -27,14 +28,14 @@ def run_one_epoch(model, dataloader, criterion, device, trainer=None, state="tra
 		raise ValueError("training needs a trainer / optimizer (zero_grad, step) or a graphed step")
 	total_loss = torch.zeros((), dtype=torch.float32, device=device)
 	correct = torch.zeros((), dtype=torch.int64, device=device)
-	total, steps = 0, 0
+	total, steps, counted = 0, 0, 0
 	with torch.set_grad_enabled(is_training):
 		for x, y in dataloader:
 			x = x.to(device, non_blocking=True)
 			y = y.to(device, non_blocking=True)
 			if is_training and graphed_step is not None:
-				loss = graphed_step(x, y)
-				logits = None
+				out = graphed_step(x, y)
+				loss, logits = out if isinstance(out, tuple) else (out, None)
 			else:
 				if is_training:
 					trainer.zero_grad()
@@ -47,9 +48,10 @@ def run_one_epoch(model, dataloader, criterion, device, trainer=None, state="tra
 			total_loss += loss.detach().float()
 			if logits is not None:
 				correct += (logits.detach().argmax(dim=1) == y).sum()
+				counted += len(x)
 			total += len(x)
 			steps += 1
 	if steps == 0:
 		return 0.0, 0.0
 	# the only device -> host reads of the epoch
-	return total_loss.item() / steps, correct.item() / total
+	return total_loss.item() / steps, (correct.item() / counted if counted == total else float("nan"))
