@@ -55,7 +55,7 @@ def register_shadow(param, shadow_bf16, refresh=None):
 	re-derive the copies and call shadow_in_sync() — or raises if there is none, instead of computing with stale weights."""
 	assert shadow_bf16.dtype == torch.bfloat16 and shadow_bf16.shape == param.shape and shadow_bf16.is_contiguous()
 	pid = id(param)
-	_shadows[pid] = [weakref.ref(param, lambda _r, pid=pid: _shadows.pop(pid, None)), shadow_bf16, param._version, refresh]
+	_shadows[pid] = [weakref.ref(param, lambda _r, pid=pid, d=_shadows: d.pop(pid, None)), shadow_bf16, param._version, refresh]
 
 
 def shadow_in_sync(param):
@@ -95,7 +95,7 @@ def weight_as(w, dtype):
 		return hit[2]
 	out = cast(w.detach(), dtype)
 	wid = id(w)
-	_cast_cache[wid] = (weakref.ref(w, lambda _r, wid=wid: _cast_cache.pop(wid, None)), key, out)
+	_cast_cache[wid] = (weakref.ref(w, lambda _r, wid=wid, d=_cast_cache: d.pop(wid, None)), key, out)
 	return out
 
 
@@ -127,7 +127,7 @@ def register_transposed(wc, wt):
 	bf16 shadow) that the owner refreshes whenever the weight changes (the optimizer does, with one batched launch)."""
 	assert wt.shape == (wc.shape[1], wc.shape[0]) and wt.dtype == wc.dtype and wt.is_contiguous()
 	wid = id(wc)
-	_wt_kept[wid] = (weakref.ref(wc, lambda _r, wid=wid: _wt_kept.pop(wid, None)), wt)
+	_wt_kept[wid] = (weakref.ref(wc, lambda _r, wid=wid, d=_wt_kept: d.pop(wid, None)), wt)
 
 
 def weight_t(wc):
@@ -142,7 +142,7 @@ def weight_t(wc):
 		return hit[2]
 	out = transpose(wc)
 	wid = id(wc)
-	_wt_cache[wid] = (weakref.ref(wc, lambda _r, wid=wid: _wt_cache.pop(wid, None)), key, out)
+	_wt_cache[wid] = (weakref.ref(wc, lambda _r, wid=wid, d=_wt_cache: d.pop(wid, None)), key, out)
 	return out
 
 
@@ -160,7 +160,7 @@ def register_grad_sink(param, buffer, on_written=None):
 	same backward if the callback counts arrivals."""
 	assert buffer.dtype == torch.float32 and buffer.shape == param.shape and buffer.is_contiguous()
 	pid = id(param)
-	_grad_sinks[pid] = (weakref.ref(param, lambda _r, pid=pid: _grad_sinks.pop(pid, None)), buffer, on_written)
+	_grad_sinks[pid] = (weakref.ref(param, lambda _r, pid=pid, d=_grad_sinks: d.pop(pid, None)), buffer, on_written)
 
 
 def clear_grad_sinks():
