@@ -442,6 +442,14 @@ bool vitk_gemm_bf16_ok(const vitk_gemm_desc& d) {
 int vitk_gemm_bf16(const vitk_gemm_desc& d, hipStream_t st, bool* colsum_done) {
 	static const bool big_tiles = getenv("VITK_NO_BIG_TILE") == nullptr;  // debugging / A-B switch
 	*colsum_done = false;
+	// Problems whose 256x256 tiles leave the last round of the persistent kernel mostly empty (N = 768 at 50,432 rows: 591
+	// tiles = 2.3 rounds of 256) run on the 128x256-tile kernel, which balances the tail at half the granularity.
+	static const bool t128 = getenv("VITK_NO_T128") == nullptr;  // A-B switch
+	if (t128 && big_tiles && vitk_gemm_bf16_t128_ok(d) && d.a_colsum == nullptr) {
+		const int64_t t256 = vitk_cdiv(d.M, 256) * vitk_cdiv(d.N, 256), t128n = vitk_cdiv(d.M, 128) * vitk_cdiv(d.N, 256);
+		const int64_t r256 = vitk_cdiv(t256, 256), r128 = vitk_cdiv(t128n, 256);  // rounds in units of a CU's tile time / half of it
+		if (t256 > 256 && r128 * 10 < r256 * 2 * 9) return vitk_gemm_bf16_t128(d, st);
+	}
 	if (big_tiles && vitk_gemm_bf16_256_ok(d)) {
 		const int rc = vitk_gemm_bf16_256(d, st, colsum_done);
 		if (rc != VITK_ERR_UNSUPPORTED) return rc;
