@@ -9,9 +9,13 @@
 #include "gemm_common.h"
 
 int vitk_gemm_bf16_t128(const vitk_gemm_desc& d, hipStream_t st);
+int vitk_gemm_bf16_p8(const vitk_gemm_desc& d, hipStream_t st);
 int vitk_t128_occupancy(int lds);
 #ifdef VITK_T128_STAMPS
 void vitk_t128_set_stamps(long long* p);
+#endif
+#ifdef VITK_P8_STAMPS
+void vitk_p8_set_stamps(long long* p);
 #endif
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1); } } while (0)
@@ -41,6 +45,8 @@ int main(int argc, char** argv) {
 	std::vector<Shape> shapes = {{"qkv", 50432, 2304, 768}, {"proj", 50432, 768, 768}, {"fc_in", 50432, 3072, 768}, {"fc_out", 50432, 768, 3072},
 		{"dqkv", 50432, 768, 2304}, {"sq4k", 4096, 4096, 4096}, {"sq8k", 8192, 8192, 8192}, {"rag", 5000, 1000 - 8, 256}};
 	const int iters = argc > 1 ? atoi(argv[1]) : 10;
+	const bool use_p8 = getenv("LAB_KERNEL") && !strcmp(getenv("LAB_KERNEL"), "p8");
+	auto cand = [&](const vitk_gemm_desc& d, hipStream_t s_) { return use_p8 ? vitk_gemm_bf16_p8(d, s_) : vitk_gemm_bf16_t128(d, s_); };
 	const char* only = argc > 2 ? argv[2] : nullptr;
 	hipStream_t st;
 	CK(hipStreamCreate(&st));
@@ -74,7 +80,7 @@ int main(int argc, char** argv) {
 			d0.C = C0; d1.C = C1;
 			if (e == 1) { d0.out2 = p0; d1.out2 = p1; d0.ld_out2 = d1.ld_out2 = s.N; }
 			CK(hipMemsetAsync(C0, 0, s.M * s.N * 2, st)); CK(hipMemsetAsync(C1, 0xff, s.M * s.N * 2, st));
-			int rc0 = vitk_gemm(&d0, st), rc1 = vitk_gemm_bf16_t128(d1, st);
+			int rc0 = vitk_gemm(&d0, st), rc1 = cand(d1, st);
 			if (rc0 || rc1) { printf("%s %s: rc %d %d\n", s.name, enames[e], rc0, rc1); continue; }
 			CK(hipMemsetAsync(nd, 0, 8, st));
 			diff_kernel<<<1024, 256, 0, st>>>((const uint16_t*)C0, (const uint16_t*)C1, s.M * s.N, nd);
@@ -88,7 +94,7 @@ int main(int argc, char** argv) {
 			for (int rep = 0; rep < 3; ++rep)
 				for (int w = 0; w < 2; ++w) {
 					CK(hipEventRecord(e0, st));
-					for (int i = 0; i < iters; ++i) { if (w == 0) vitk_gemm(&d0, st); else vitk_gemm_bf16_t128(d1, st); }
+					for (int i = 0; i < iters; ++i) { if (w == 0) vitk_gemm(&d0, st); else cand(d1, st); }
 					CK(hipEventRecord(e1, st));
 					CK(hipEventSynchronize(e1));
 					float ms; CK(hipEventElapsedTime(&ms, e0, e1));
@@ -126,8 +132,39 @@ int main(int argc, char** argv) {
 				printf("\n");
 			}
 #endif
+#ifdef VITK_P8_STAMPS
+			if (use_p8) {
+				const int nb = 1024;
+				const size_t bytes = (nb * 16 * 4 + 8 * 16) * 8;
+				long long* sd;
+				CK(hipMalloc(&sd, bytes));
+				CK(hipMemset(sd, 0, bytes));
+				vitk_p8_set_stamps(sd);
+				vitk_gemm_bf16_p8(d1, st);
+				CK(hipStreamSynchronize(st));
+				vitk_p8_set_stamps(nullptr);
+				std::vector<long long> hs(bytes / 8);
+				CK(hipMemcpy(hs.data(), sd, bytes, hipMemcpyDeviceToHost));
+				hipFree(sd);
+				double ml[16] = {0}, ep[16] = {0}; int cnt[16] = {0};
+				for (int b = 0; b < nb; ++b) for (int r = 0; r < 16; ++r) {
+					const long long* q = &hs[(b * 16 + r) * 4];
+					if (!q[0]) continue;
+					ml[r] += q[1] - q[0]; ep[r] += q[2] - q[1]; cnt[r]++;
+				}
+				printf("   stamps:");
+				for (int r = 0; r < 12 && cnt[r]; ++r) printf(" r%d[n=%d ml %.0f ep %.0f]", r, cnt[r], ml[r] / cnt[r], ep[r] / cnt[r]);
+				printf("\n");
+				for (int w = 0; w < 8; w += 4) {
+					const long long* q = &hs[nb * 16 * 4 + w * 16];
+					printf("   wave %d K step 3, deltas between barriers:", w);
+					for (int i = 1; i < 5; ++i) printf(" %lld", q[i] - q[i - 1]);
+					printf("  (total %lld)\n", q[4] - q[0]);
+				}
+			}
+#endif
 			const double fl = 2.0 * s.M * s.N * s.K / 1e9;
-			printf("%-7s %-9s M=%lld N=%lld K=%lld: old %8.1f us %7.1f TF | t128 %8.1f us %7.1f TF | mismatches %llu\n", s.name, enames[e], (long long)s.M, (long long)s.N,
+			printf("%-7s %-9s M=%lld N=%lld K=%lld: old %8.1f us %7.1f TF | new %8.1f us %7.1f TF | mismatches %llu\n", s.name, enames[e], (long long)s.M, (long long)s.N,
 				(long long)s.K, best[0] * 1e3, fl / best[0], best[1] * 1e3, fl / best[1], h);
 			fflush(stdout);
 		}

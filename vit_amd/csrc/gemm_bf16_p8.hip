@@ -1,0 +1,332 @@
+// bf16 MFMA GEMM, K-major x K-major operands, bf16 output (forward and input-gradient GEMMs of nn.Linear,
+// layers/transformers.py:46-54 and layers/attention.py:28,47 of the reference): persistent 256 x 256 x 64 tiles, one
+// 512-thread workgroup per CU, built around a DEEP operand pipeline instead of one "wait for everything + barrier" per
+// K step.
+//
+// Wave w = (wr, wc) = (w >> 2, w & 3) owns rows wr * 128 + [0, 128) and columns wc * 64 + [0, 64) of the tile: 8 x 4
+// tiles of v_mfma_f32_16x16x32_bf16, 128 accumulator registers, cut into four QUADRANTS of 64 rows x 32 columns
+// (row half h, column half h').  An operand K step (256 rows x 64 k) is staged as two HALF-TILES of 16 KiB: A_h holds
+// row half h of BOTH wave rows (LDS row wr * 64 + i <-> tile row wr * 128 + h * 64 + i), B_h' column half h' of all four
+// wave columns (LDS row wc * 32 + j <-> tile column wc * 64 + h' * 32 + j), so that one quadrant of every wave needs exactly
+// one A and one B half-tile.  LDS holds two K steps (2 x 4 half-tiles, 128 KiB) + 8 x 4 KiB of epilogue images.
+//
+// A K step runs as four phases, one quadrant each (16 MFMAs per wave):
+//     phase 1: read B_0, A_0   quadrant (0,0)        phase 3: read A_1   quadrant (1,1)
+//     phase 2: read B_1        quadrant (0,1)        phase 4: read B_0   quadrant (1,0)
+// Every phase also issues the LDS-DMA (global_load_lds_dwordx4, two requests per lane) of ONE half-tile: the one whose
+// last fragment read was retired in the phase before, refilled for the K step that will use that buffer next
+// (phase 1: B_0 of step u+1, phases 2-4: A_0, B_1, A_1 of step u+2).  The only wait on that stream is one counted
+// s_waitcnt vmcnt(6) per K step (phase 4): it leaves the three newest half-tiles in flight, so the memory pipeline never
+// drains, and operand requests run 1.75 K steps ahead of their use, across tile boundaries too.
+//
+// The two wave rows (waves 0-3 / 4-7, one wave of each per SIMD) run half a phase apart: each phase is
+// {fragment reads + DMA issue, barrier, 16 MFMAs, barrier}, and the second wave row starts one barrier late, so on every
+// SIMD one wave is in its MFMA part while its partner is in its load part.
+//
+// Ordering rules the schedule obeys (an LDS-DMA is ordered for a reader only by the issuer's counted vmcnt followed by a
+// barrier the reader passes; an LDS read is retired only by the reading wave's lgkmcnt):
+//   - every wave retires a phase's fragment reads (lgkmcnt(0)) BEFORE that phase's first barrier, so a half-tile may be
+//     refilled by any wave from the next phase on;
+//   - the vmcnt(6) sits before phase 4's FIRST barrier, so that both wave rows have passed a barrier behind every wave's
+//     wait before the first read of the next K step (phase 1 of either wave row).
+#include <cstdlib>
+#include <type_traits>
+
+#include "gemm_common.h"
+#include "gemm_epilogue_wave.h"
+
+namespace {
+
+constexpr int BM = 256, BN = 256, BK = 64, NTHREADS = 512;
+constexpr int HALF_BYTES = 128 * BK * 2;      // 16 KiB
+constexpr int STEP_BYTES = 4 * HALF_BYTES;    // [A_0][A_1][B_0][B_1]
+constexpr int EPI_OFF = 2 * STEP_BYTES;
+constexpr int EW_BYTES = 16 * 64 * 4;
+constexpr int LDS_BYTES = EPI_OFF + 8 * EW_BYTES;  // 163,840 B: the whole LDS of a CU
+
+typedef __attribute__((address_space(3))) void* lds_void_p;
+typedef const __attribute__((address_space(1))) void* gbl_void_p;
+
+__device__ __forceinline__ int off_k(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
+__device__ __forceinline__ uint32_t lds_addr(const char* p) { return (uint32_t)(uintptr_t)(lds_void_p)(void*)p; }
+
+// 16-byte LDS read issued as inline asm (NOT waited for: the caller retires it with an s_waitcnt that names `dst`).  Plain
+// LDS loads would do: but behind an LDS-DMA still in flight the compiler puts s_waitcnt vmcnt(0) in front of them.
+__device__ __forceinline__ void lds_read128(bf16x8& dst, uint32_t addr, int offset) {
+	asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(offset));
+}
+
+struct P8Args {
+	GemmDev g;
+	int tiles_m, tiles_n;
+	int vec8;  // epilogue operands / outputs may be accessed 16 bytes wide
+#ifdef VITK_P8_STAMPS
+	long long* stamps;
+#endif
+};
+
+#ifdef VITK_P8_STAMPS
+long long* g_p8_stamps = nullptr;
+#define P8STAMP(slot) \
+	if (a.stamps != nullptr && tid == 0 && round < 16) a.stamps[((int64_t)blockIdx.x * 16 + round) * 4 + (slot)] = __builtin_readcyclecounter()
+#define PH(n) \
+	if (a.stamps != nullptr && kt == 3 && round == 0) ph[n] = __builtin_readcyclecounter()
+#else
+#define P8STAMP(slot)
+#define PH(n)
+#endif
+
+template <int EPI, int ACT>
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_p8_kernel(P8Args a) {
+	// memory operations an epilogue issues at least (per wave-lane: 16 output stores, + 16 operand loads with an aux operand)
+	constexpr int N_EPI = (EPI == VITK_EPI_RESIDUAL || EPI == VITK_EPI_ACTGRAD) ? 32 : 16;
+	extern __shared__ __attribute__((aligned(16))) char smem[];
+	const GemmDev& g = a.g;
+	const int tid = threadIdx.x, lane = tid & 63;
+	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+	const int wr = wave >> 2, wc = wave & 3;
+	const int ntiles = a.tiles_m * a.tiles_n;
+	const int nblk = gridDim.x;  // a multiple of 8
+	const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+	constexpr int GM = 4;
+	const int per_group = GM * a.tiles_n;
+
+	// tile of this workgroup in a round: consecutive tiles (in grouped order) go to workgroups that share an XCD
+	auto tile_of = [&](int round, int64_t& m0, int64_t& n0) -> bool {
+		const int base = round * nblk;
+		const int n = min(nblk, ntiles - base);
+		if (n <= 0) return false;
+		const int q = n >> 3, r = n & 7;
+		if (idx >= q + (xcd < r ? 1 : 0)) return false;
+		const int t = base + (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+		const int group = t / per_group;
+		const int first_m = group * GM;
+		const int gsz = min(a.tiles_m - first_m, GM);
+		const int tm = first_m + (t % per_group) % gsz;
+		const int tn = (t % per_group) / gsz;
+		m0 = (int64_t)tm * BM;
+		n0 = (int64_t)tn * BN;
+		return true;
+	};
+
+	const int nt = (int)(g.K / BK);  // >= 2
+	const bf16_t* A = reinterpret_cast<const bf16_t*>(g.A);
+	const bf16_t* B = reinterpret_cast<const bf16_t*>(g.B);
+	char* const img = smem + EPI_OFF + wave * EW_BYTES;
+	const uint32_t lds0 = lds_addr(smem);
+
+	// LDS-DMA source offset of a lane inside an 8-row piece (row lane >> 3, 16-byte chunk (lane & 7) ^ row)
+	const int pr = lane >> 3, pch = (lane & 7) ^ (lane >> 3);
+	const uint32_t a_voff = (uint32_t)(pr * (int)g.lda + 8 * pch) * 2u;
+	const uint32_t b_voff = (uint32_t)(pr * (int)g.ldb + 8 * pch) * 2u;
+
+	// One half-tile: 16 pieces of 8 rows, two per wave.  which: 0 = A_0, 1 = A_1, 2 = B_0, 3 = B_1.
+	auto stage_half = [&](int buf, int which, int64_t tm0, int64_t tn0, int k0) {
+		char* dst = smem + buf * STEP_BYTES + which * HALF_BYTES;
+#pragma unroll
+		for (int j = 0; j < 2; ++j) {
+			const int p = 2 * wave + j;
+			if (which < 2) {
+				const int64_t row0 = tm0 + (p >> 3) * 128 + which * 64 + 8 * (p & 7);
+				const char* src = reinterpret_cast<const char*>(A + row0 * g.lda + k0) + a_voff;
+				__builtin_amdgcn_global_load_lds((gbl_void_p)src, (lds_void_p)(dst + p * 1024), 16, 0, 0);
+			} else {
+				const int64_t col0 = tn0 + (p >> 2) * 64 + (which - 2) * 32 + 8 * (p & 3);
+				const char* src = reinterpret_cast<const char*>(B + col0 * g.ldb + k0) + b_voff;
+				__builtin_amdgcn_global_load_lds((gbl_void_p)src, (lds_void_p)(dst + p * 1024), 16, 0, 0);
+			}
+		}
+	};
+
+	// fragment read addresses inside a half-tile: row (lane & 15) of a 16-row block, 16-byte chunk (lane >> 4) ^ (row & 7);
+	// the second half of the K step is the same address with bit 6 flipped (chunk + 4), the next 16 rows are +2048
+	const uint32_t a_lane = (uint32_t)off_k(wr * 64 + (lane & 15), lane >> 4);
+	const uint32_t b_lane = (uint32_t)off_k(wc * 32 + (lane & 15), lane >> 4);
+
+	int64_t m0 = 0, n0 = 0;
+	bool have = tile_of(0, m0, n0);
+	if (!have) return;  // (grids never exceed the tile count)
+	int64_t nm0 = m0, nn0 = n0;  // the tile after this one; after the last tile its operands are fetched again (nobody reads them)
+	bool nxt = tile_of(1, nm0, nn0);
+
+	// K step `kt + d` of the current tile, or the matching step of the next tile
+	auto stage_ahead = [&](int buf, int which, int kt, int d) {
+		const int k = kt + d;
+		const bool cur = k < nt;
+		stage_half(buf, which, cur ? m0 : nm0, cur ? n0 : nn0, (cur ? k : k - nt) * BK);
+	};
+
+	// prologue: all of K step 0, and A_0, B_0, B_1 of K step 1 (its A_1 goes out in phase A of step 0)
+	stage_ahead(0, 2, 0, 0);
+	stage_ahead(0, 0, 0, 0);
+	stage_ahead(0, 3, 0, 0);
+	stage_ahead(0, 1, 0, 0);
+	stage_ahead(1, 0, 0, 1);
+	stage_ahead(1, 2, 0, 1);
+	stage_ahead(1, 3, 0, 1);
+	asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+	__builtin_amdgcn_s_barrier();
+
+	int par = 0;  // LDS buffer of the current K step
+	for (int round = 0; have; ++round) {
+		P8STAMP(0);
+		f32x4 acc[8][4];
+#pragma unroll
+		for (int i = 0; i < 8; ++i)
+#pragma unroll
+			for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+		if (wr == 1) __builtin_amdgcn_s_barrier();  // the second wave row runs half a phase behind the first
+#ifdef VITK_P8_STAMPS
+		long long ph[5] = {0};
+#endif
+		for (int kt = 0; kt < nt; ++kt) {
+			PH(0);
+			const uint32_t sb = lds0 + par * STEP_BYTES;
+			bf16x8 xa[4][2], xb[4][2];
+			// ---- phase A: B_0, B_1, A_0 -> row half 0 (quadrants (0,0), (0,1)); DMA: A_1 of the next K step ----
+#pragma unroll
+			for (int j = 0; j < 4; ++j)
+#pragma unroll
+				for (int s = 0; s < 2; ++s) lds_read128(xb[j][s], (sb + (2 + (j >> 1)) * HALF_BYTES + b_lane) ^ (s << 6), 2048 * (j & 1));
+#pragma unroll
+			for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+				for (int s = 0; s < 2; ++s) lds_read128(xa[mi][s], (sb + a_lane) ^ (s << 6), 2048 * mi);
+			// all but the six newest requests (A_0, B_0, B_1 of the next K step) have landed: this step's A_1 is in LDS.  In
+			// the first K step of a tile the previous epilogue's loads and stores are newer still and stay in flight too.
+			if (kt == 0 && round > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 + N_EPI) : "memory");
+			else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+			stage_ahead(par ^ 1, 1, kt, 1);
+			asm volatile("s_waitcnt lgkmcnt(0)"
+						 : "+v"(xb[0][0]), "+v"(xb[0][1]), "+v"(xb[1][0]), "+v"(xb[1][1]), "+v"(xb[2][0]), "+v"(xb[2][1]), "+v"(xb[3][0]), "+v"(xb[3][1]), "+v"(xa[0][0]),
+						   "+v"(xa[0][1]), "+v"(xa[1][0]), "+v"(xa[1][1]), "+v"(xa[2][0]), "+v"(xa[2][1]), "+v"(xa[3][0]), "+v"(xa[3][1])
+						 :
+						 : "memory");
+			__builtin_amdgcn_s_barrier();
+			PH(1);
+			__builtin_amdgcn_sched_barrier(0);
+			__builtin_amdgcn_s_setprio(1);
+#pragma unroll
+			for (int s = 0; s < 2; ++s)
+#pragma unroll
+				for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+					for (int j = 0; j < 4; ++j) acc[mi][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xb[j][s], xa[mi][s], acc[mi][j], 0, 0, 0);
+			__builtin_amdgcn_s_setprio(0);
+			__builtin_amdgcn_sched_barrier(0);
+			__builtin_amdgcn_s_barrier();
+			PH(2);
+			// ---- phase B: A_1 -> row half 1 (quadrants (1,0), (1,1)); DMA: A_0, B_0, B_1 of the K step after next ----
+#pragma unroll
+			for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+				for (int s = 0; s < 2; ++s) lds_read128(xa[mi][s], (sb + HALF_BYTES + a_lane) ^ (s << 6), 2048 * mi);
+			// all but the two newest requests (A_1 of the next K step) have landed: the next K step's A_0, B_0, B_1 are in LDS
+			if (kt == 0 && round > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 + N_EPI) : "memory");
+			else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+			stage_ahead(par, 0, kt, 2);
+			stage_ahead(par, 2, kt, 2);
+			stage_ahead(par, 3, kt, 2);
+			asm volatile("s_waitcnt lgkmcnt(0)"
+						 : "+v"(xa[0][0]), "+v"(xa[0][1]), "+v"(xa[1][0]), "+v"(xa[1][1]), "+v"(xa[2][0]), "+v"(xa[2][1]), "+v"(xa[3][0]), "+v"(xa[3][1])
+						 :
+						 : "memory");
+			__builtin_amdgcn_s_barrier();
+			PH(3);
+			__builtin_amdgcn_sched_barrier(0);
+			__builtin_amdgcn_s_setprio(1);
+#pragma unroll
+			for (int s = 0; s < 2; ++s)
+#pragma unroll
+				for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+					for (int j = 0; j < 4; ++j) acc[4 + mi][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xb[j][s], xa[mi][s], acc[4 + mi][j], 0, 0, 0);
+			__builtin_amdgcn_s_setprio(0);
+			__builtin_amdgcn_sched_barrier(0);
+			__builtin_amdgcn_s_barrier();
+			PH(4);
+			par ^= 1;
+		}
+		// both wave rows run their epilogues side by side: the first waits here for the second's last MFMA part
+		if (wr == 0) __builtin_amdgcn_s_barrier();
+		P8STAMP(1);
+		asm volatile("" ::: "memory");
+		__builtin_amdgcn_sched_barrier(0);
+		const int64_t m0w = m0 + wr * 128, n0w = n0 + wc * 64;
+		EpiRegs er;  // (the host only launches this kernel on whole tiles with 16-byte accessible operands)
+		epilogue_prefetch<EPI>(g, er, true, n0w, lane);
+		epilogue_wave<EPI, ACT, false>(g, acc, er, true, img, m0w, n0w, lane);
+		P8STAMP(2);
+#ifdef VITK_P8_STAMPS
+		if (a.stamps != nullptr && round == 0 && lane == 0 && blockIdx.x == 8)
+			for (int i = 0; i < 5; ++i) a.stamps[1024 * 16 * 4 + wave * 16 + i] = ph[i];
+#endif
+		m0 = nm0;
+		n0 = nn0;
+		have = nxt;
+		nxt = tile_of(round + 2, nm0, nn0);  // (leaves nm0, nn0 alone when there is none)
+	}
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the last (unused) DMA must not outlive the workgroup's LDS
+}
+
+int p8_blocks() {
+	static int n = 0;
+	if (n == 0) {
+		int dev = 0, cus = 0;
+		if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 8) cus = 256;
+		n = cus & ~7;
+	}
+	return n;
+}
+
+template <int EPI, int ACT>
+int launch_p8(const P8Args& a, hipStream_t st) {
+	static bool attr = false;
+	if (!attr) {
+		hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_p8_kernel<EPI, ACT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+		if (e != hipSuccess) return VITK_ERR_HIP - (int)e;
+		attr = true;
+	}
+	const int64_t tiles = (int64_t)a.tiles_m * a.tiles_n;
+	int blocks = p8_blocks();
+	if (tiles < blocks) blocks = (int)((tiles + 7) & ~7ll);
+	hipLaunchKernelGGL((gemm_bf16_p8_kernel<EPI, ACT>), dim3((unsigned)blocks), dim3(NTHREADS), LDS_BYTES, st, a);
+	VITK_CHECK_LAUNCH();
+	return VITK_OK;
+}
+
+}  // namespace
+
+#ifdef VITK_P8_STAMPS
+void vitk_p8_set_stamps(long long* p) { g_p8_stamps = p; }
+#endif
+
+bool vitk_gemm_bf16_p8_ok(const vitk_gemm_desc& d) {
+	if (d.patch_grid > 0 || d.tokens_per_image > 0 || d.K % BK != 0 || d.K < 2 * BK) return false;
+	if (d.a_layout != VITK_K_MAJOR || d.b_layout != VITK_K_MAJOR) return false;
+	if (d.in_dtype != VITK_BF16 || d.out_dtype != VITK_BF16 || d.accumulate) return false;
+	if (d.M % BM != 0 || d.N % BN != 0) return false;  // whole tiles only: the kernel has no edge handling
+	auto al16 = [](const void* p) { return p == nullptr || vitk_aligned(p, 16); };
+	if (d.ldc % 8 != 0 || d.ld_aux % 8 != 0 || d.ld_out2 % 8 != 0 || !al16(d.C) || !al16(d.bias) || !al16(d.gamma) || !al16(d.aux) || !al16(d.out2)) return false;
+	if (d.lda % 8 != 0 || d.ldb % 8 != 0 || !al16(d.A) || !al16(d.B)) return false;
+	return true;
+}
+
+int vitk_gemm_bf16_p8(const vitk_gemm_desc& d, hipStream_t st) {
+	P8Args a{};
+	a.g = make_gemm_dev(d);
+	a.tiles_m = (int)vitk_cdiv(d.M, BM);
+	a.tiles_n = (int)vitk_cdiv(d.N, BN);
+#ifdef VITK_P8_STAMPS
+	a.stamps = g_p8_stamps;
+#endif
+	if (!vitk_gemm_bf16_p8_ok(d)) return VITK_ERR_UNSUPPORTED;
+	a.vec8 = 1;
+	switch (d.epilogue) {
+		case VITK_EPI_NONE: return launch_p8<VITK_EPI_NONE, -1>(a, st);
+		case VITK_EPI_ACT: return d.act == VITK_ACT_GELU ? launch_p8<VITK_EPI_ACT, VITK_ACT_GELU>(a, st) : launch_p8<VITK_EPI_ACT, -1>(a, st);
+		case VITK_EPI_RESIDUAL: return launch_p8<VITK_EPI_RESIDUAL, -1>(a, st);
+		case VITK_EPI_ACTGRAD: return d.act == VITK_ACT_GELU ? launch_p8<VITK_EPI_ACTGRAD, VITK_ACT_GELU>(a, st) : launch_p8<VITK_EPI_ACTGRAD, -1>(a, st);
+		default: return VITK_ERR_UNSUPPORTED;
+	}
+}

@@ -22,6 +22,7 @@
 #include <type_traits>
 
 #include "gemm_common.h"
+#include "gemm_epilogue_wave.h"
 
 namespace {
 
@@ -33,7 +34,6 @@ constexpr int EPI_OFF = B_OFF + B_BYTES;
 constexpr int EW_BYTES = 16 * 64 * 4;  // 4 KiB per wave: 16 rows x 64 columns of float, 16-byte chunk ^= row
 constexpr int LDS_BYTES = EPI_OFF + 4 * EW_BYTES;  // 81,920 B: two workgroups fill the CU's 160 KiB exactly
 
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void* lds_void_p;
 typedef const __attribute__((address_space(1))) void* gbl_void_p;
 
@@ -67,14 +67,6 @@ __device__ __forceinline__ void stage_piece(char* tile, const bf16_t* __restrict
 	__builtin_amdgcn_global_load_lds((gbl_void_p)src, (lds_void_p)(tile + piece * 1024), 16, 0, 0);
 }
 
-template <int I, int N, typename F>
-__device__ __forceinline__ void static_for(F&& f) {
-	if constexpr (I < N) {
-		f(std::integral_constant<int, I>{});
-		static_for<I + 1, N>(f);
-	}
-}
-
 struct T128Args {
 	GemmDev g;
 	int tiles_m, tiles_n;
@@ -90,154 +82,6 @@ template <int ACT>
 __device__ __forceinline__ float act_fwd1(float u, int act_rt) {
 	if constexpr (ACT == VITK_ACT_GELU) return gelu_bf16(u);
 	else return act_apply(u, act_rt);
-}
-
-// Per-tile epilogue operands a lane keeps in registers: bias / LayerScale of its 8 columns.
-struct EpiRegs {
-	float bias8[8], gamma8[8];
-};
-
-template <int EPI>
-__device__ __forceinline__ void epilogue_prefetch(const T128Args& a, EpiRegs& er, bool full, int64_t n0w, int lane) {
-	const GemmDev& g = a.g;
-	const int64_t nb = n0w + 8 * (lane & 7);
-#pragma unroll
-	for (int e = 0; e < 8; ++e) {
-		er.bias8[e] = 0.f;
-		er.gamma8[e] = 1.f;
-	}
-	if (!full) return;
-	if (g.bias != nullptr) {
-		load_vec<float, 4>(g.bias + nb, *reinterpret_cast<float(*)[4]>(&er.bias8[0]));
-		load_vec<float, 4>(g.bias + nb + 4, *reinterpret_cast<float(*)[4]>(&er.bias8[4]));
-	}
-	if (EPI == VITK_EPI_RESIDUAL && g.gamma != nullptr) {
-		load_vec<float, 4>(g.gamma + nb, *reinterpret_cast<float(*)[4]>(&er.gamma8[0]));
-		load_vec<float, 4>(g.gamma + nb + 4, *reinterpret_cast<float(*)[4]>(&er.gamma8[4]));
-	}
-}
-
-// Epilogue of one wave's 128 x 64 accumulator tile, 16 rows (one row of MFMA tiles) at a time: the wave writes the
-// four accumulator fragments (accumulator layout: 16 rows x 16 bytes per wave-instruction) into its private image,
-// reads them back as rows (each lane 8 consecutive columns of one row) and does the fused arithmetic there, so that
-// operands arrive and results leave in 16-byte accesses, 8 rows x 128 contiguous bytes per wave-instruction.  LDS
-// operations of one wave complete in order, so no barrier is needed.  `full`: wave-uniform, the wave's 128 x 64 block
-// lies inside M x N and every operand may be accessed 16 bytes wide.
-template <int EPI, int ACT>
-__device__ __forceinline__ void epilogue_wave(const T128Args& a, const f32x4 (&acc)[8][4], const EpiRegs& er, bool full, char* img, int64_t m0, int64_t n0w, int lane) {
-	const GemmDev& g = a.g;
-	const int c8 = lane & 7, r8 = lane >> 3;
-	const int64_t nb = n0w + 8 * c8;
-	const bf16_t* aux = reinterpret_cast<const bf16_t*>(g.aux);
-	bf16_t* out2 = reinterpret_cast<bf16_t*>(g.out2);
-	bf16_t* outp = reinterpret_cast<bf16_t*>(g.C);
-	constexpr bool HAS_AUX = EPI == VITK_EPI_RESIDUAL || EPI == VITK_EPI_ACTGRAD;
-	const int wrow = lane & 15;
-	auto write_rows = [&](auto ic) {
-		constexpr int i = decltype(ic)::value;
-#pragma unroll
-		for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(img + wrow * 256 + (((4 * j + (lane >> 4)) ^ wrow) << 4)) = acc[i][j];
-	};
-	if (!full) {
-		static_for<0, 8>([&](auto ic) {
-			constexpr int i = decltype(ic)::value;
-			write_rows(ic);
-#pragma unroll 1
-			for (int idx = lane; idx < 16 * 64; idx += 64) {
-				const int row = idx >> 6, col = idx & 63;
-				const int64_t m = m0 + 16 * i + row, n = n0w + col;
-				const float v = *reinterpret_cast<const float*>(img + row * 256 + ((((col >> 2) ^ row) << 4) | ((col & 3) << 2)));
-				if (m < g.M && n < g.N) epi_store1<bf16_t, bf16_t, EPI, ACT>(g, m, n, v);
-			}
-		});
-		return;
-	}
-	const bool drop_on = g.drop[0].thr16 != 0;
-	// Operand rows (residual / pre-activation) of the NEXT 16 rows are requested one step ahead as inline asm (a
-	// wave-uniform row base in scalar registers plus one 32-bit lane offset) and retired by a COUNTED wait that leaves the
-	// newer requests and the stores in flight; written as plain loads the compiler sinks them to their uses and waits
-	// vmcnt(0) there, i.e. for every store issued before them.  The "memory" clobbers keep the stores between the asm
-	// statements, which the counts rely on.
-	u32x4 auxv[2][2];
-	const uint32_t aux_voff = (uint32_t)(r8 * (int)g.ld_aux + 8 * c8) * 2u;
-	constexpr int NST = (EPI == VITK_EPI_ACT) ? 4 : 2;  // stores per 16 rows when out2 is written (the count below assumes the maximum is fine: see wait)
-	auto request = [&](int i, u32x4(&dst)[2]) {
-#pragma unroll
-		for (int it = 0; it < 2; ++it) {
-			const bf16_t* rowbase = aux + (m0 + 16 * i + 8 * it) * g.ld_aux + n0w;  // wave-uniform
-			asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst[it]) : "v"(aux_voff), "s"(rowbase) : "memory");
-		}
-	};
-	if (HAS_AUX) request(0, auxv[0]);
-	static_for<0, 8>([&](auto ic) {
-		constexpr int i = decltype(ic)::value;
-		if (HAS_AUX) {
-			if constexpr (i < 7) request(i + 1, auxv[(i + 1) & 1]);
-			u32x4(&cur)[2] = auxv[i & 1];
-			// in flight behind the rows needed now: the 2 stores of the previous step (i > 0) and the 2 requests just issued (i < 7)
-			if constexpr (i == 0) asm volatile("s_waitcnt vmcnt(2)" : "+v"(cur[0]), "+v"(cur[1])::"memory");
-			else if constexpr (i < 7) asm volatile("s_waitcnt vmcnt(4)" : "+v"(cur[0]), "+v"(cur[1])::"memory");
-			else asm volatile("s_waitcnt vmcnt(2)" : "+v"(cur[0]), "+v"(cur[1])::"memory");
-		}
-		write_rows(ic);
-#pragma unroll
-		for (int it = 0; it < 2; ++it) {
-			const int row = 8 * it + r8;
-			const int64_t m = m0 + 16 * i + row;
-			const f32x4 lo = *reinterpret_cast<const f32x4*>(img + row * 256 + (((2 * c8) ^ row) << 4));
-			const f32x4 hi = *reinterpret_cast<const f32x4*>(img + row * 256 + (((2 * c8 + 1) ^ row) << 4));
-			float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-#pragma unroll
-			for (int e = 0; e < 8; ++e) v[e] += er.bias8[e];
-			float keep[8];
-			if (EPI != VITK_EPI_NONE && drop_on) {  // fused dropout (wave-uniform branch)
-				drop_keep_n<8>(g, m, nb, keep);
-				if (EPI != VITK_EPI_ACT) {
-#pragma unroll
-					for (int e = 0; e < 8; ++e) v[e] *= keep[e];
-				}
-			}
-			if (EPI == VITK_EPI_ACT) {
-				if (out2 != nullptr) {
-					bf16x8 pre;
-#pragma unroll
-					for (int e = 0; e < 8; ++e) {
-						pre[e] = (bf16_t)v[e];
-						v[e] = (float)pre[e];  // the activation sees the pre-activation as stored
-					}
-					*reinterpret_cast<bf16x8*>(out2 + m * g.ld_out2 + nb) = pre;
-				}
-				if constexpr (ACT == VITK_ACT_GELU) {
-					gelu_bf16_n<8>(v);
-				} else {
-#pragma unroll
-					for (int e = 0; e < 8; ++e) v[e] = act_apply(v[e], g.act);
-				}
-				if (drop_on) {
-#pragma unroll
-					for (int e = 0; e < 8; ++e) v[e] *= keep[e];
-				}
-			} else if (EPI == VITK_EPI_RESIDUAL) {
-#pragma unroll
-				for (int e = 0; e < 8; ++e) v[e] = (float)__builtin_bit_cast(bf16x8, auxv[i & 1][it])[e] + er.gamma8[e] * v[e];
-			} else if (EPI == VITK_EPI_ACTGRAD) {
-				float u[8];
-#pragma unroll
-				for (int e = 0; e < 8; ++e) u[e] = (float)__builtin_bit_cast(bf16x8, auxv[i & 1][it])[e];
-				if constexpr (ACT == VITK_ACT_GELU) {
-					gelu_deriv_bf16_n<8>(v, u);
-				} else {
-#pragma unroll
-					for (int e = 0; e < 8; ++e) v[e] *= act_deriv(u[e], g.act);
-				}
-			}
-			bf16x8 pk;
-#pragma unroll
-			for (int e = 0; e < 8; ++e) pk[e] = (bf16_t)v[e];
-			*reinterpret_cast<bf16x8*>(outp + m * g.ldc + nb) = pk;
-		}
-	});
-	(void)NST;
 }
 
 #ifdef VITK_T128_STAMPS
@@ -377,8 +221,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_t128_kernel(T128Args a)
 		__builtin_amdgcn_sched_barrier(0);
 		const bool full = a.vec8 && n0 + wn + 64 <= g.N && m0 + TM <= g.M;
 		EpiRegs er;
-		epilogue_prefetch<EPI>(a, er, full, n0 + wn, lane);
-		epilogue_wave<EPI, ACT>(a, acc, er, full, img, m0, n0 + wn, lane);
+		epilogue_prefetch<EPI>(g, er, full, n0 + wn, lane);
+		epilogue_wave<EPI, ACT>(g, acc, er, full, img, m0, n0 + wn, lane);
 		STAMP(2);
 #ifdef VITK_T128_STAMPS
 		if (a.stamps != nullptr && tid == 0 && round < 16) {

@@ -184,5 +184,7 @@ bool vitk_gemm_bf16_ok(const vitk_gemm_desc& d);
 int vitk_gemm_bf16_128(const vitk_gemm_desc& d, hipStream_t st, bool* colsum_done = nullptr);  // the 128x128 kernel, whatever the shape
 bool vitk_gemm_bf16_256_ok(const vitk_gemm_desc& d);  // large-tile LDS-DMA kernel (needs K % 64 == 0, M, N >= 256)
 int vitk_gemm_bf16_256(const vitk_gemm_desc& d, hipStream_t st, bool* colsum_done);
+bool vitk_gemm_bf16_p8_ok(const vitk_gemm_desc& d);  // persistent 256x256 kernel with the deep operand pipeline (whole tiles, K-major x K-major, bf16 out)
+int vitk_gemm_bf16_p8(const vitk_gemm_desc& d, hipStream_t st);
 bool vitk_gemm_bf16_t128_ok(const vitk_gemm_desc& d);  // 128x256-tile kernel, two workgroups per CU (K-major x K-major, bf16 out, K % 64 == 0)
 int vitk_gemm_bf16_t128(const vitk_gemm_desc& d, hipStream_t st);
