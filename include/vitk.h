@@ -34,6 +34,7 @@ enum vitk_status {
 	VITK_ERR_ALIGN = -3,      /* pointer / leading dimension not aligned as the kernel requires */
 	VITK_ERR_NULL = -4,       /* a required pointer is null */
 	VITK_ERR_UNSUPPORTED = -5,/* combination of options not implemented */
+	VITK_ERR_SCRATCH = -6,    /* the problem exceeds the fixed scratch of a *_noalloc entry point */
 	VITK_ERR_HIP = -1000      /* -1000 - hipError_t */
 };
 
@@ -183,6 +184,19 @@ int vitk_attention_bwd_dropout(const void* dout, const void* q, const void* k, c
 	int64_t B, int64_t n_head, int64_t Sq, int64_t Skv, int64_t dh,
 	int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t lddq, int64_t lddk, int64_t lddv,
 	float scale, float dropout_p, uint64_t seed, float* scratch, int dtype, void* stream);
+
+/* vitk_attention_bwd_dropout for callers that cannot allocate device memory and have no buffer to hand in as `scratch`
+ * (code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc).  It has no counterpart in the
+ * reference.  The 2 * B * n_head * Sq floats of scratch come from a fixed 8 MiB array inside the library's device image
+ * (one copy per GPU, held until the process ends); problems with 2 * B * n_head * Sq > 2,097,152 return
+ * VITK_ERR_SCRATCH.  The call allocates and frees nothing.  All calls on one GPU share the array, so calls that may
+ * overlap in time (different streams) race; the first call on a device looks the array's address up (do that call
+ * outside stream capture).  dropout_p = 0 is the plain backward. */
+int vitk_attention_bwd_noalloc(const void* dout, const void* q, const void* k, const void* v, const void* out, const float* lse,
+	void* dq, void* dk, void* dv,
+	int64_t B, int64_t n_head, int64_t Sq, int64_t Skv, int64_t dh,
+	int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t lddq, int64_t lddk, int64_t lddv,
+	float scale, float dropout_p, uint64_t seed, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Bandwidth-bound elementwise / reduction kernels.

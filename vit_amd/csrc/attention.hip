@@ -2,6 +2,8 @@
 // the generic vector-ALU kernels.
 #include "attention.h"
 
+#include <mutex>
+
 static int check_common(const AttnArgs& a) {
 	VITK_REQUIRE(a.B > 0 && a.n_head > 0 && a.Sq > 0 && a.Skv > 0 && a.dh > 0, VITK_ERR_SHAPE);
 	VITK_REQUIRE(a.dh <= 64, VITK_ERR_SHAPE);
@@ -73,5 +75,47 @@ extern "C" int vitk_attention_bwd(const void* dout, const void* q, const void* k
 	void* dk, void* dv, int64_t B, int64_t n_head, int64_t Sq, int64_t Skv, int64_t dh, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
 	int64_t lddq, int64_t lddk, int64_t lddv, float scale, float* scratch, int dtype, void* stream) {
 	return vitk_attention_bwd_dropout(dout, q, k, v, out, lse, dq, dk, dv, B, n_head, Sq, Skv, dh, ldq, ldk, ldv, ldo, lddq, lddk, lddv, scale, 0.f, 0, scratch,
+		dtype, stream);
+}
+
+// ---- the backward for callers that cannot allocate ----------------------------------------------------------------
+// Same computation as vitk_attention_bwd_dropout with the softmax-statistics scratch (2 * B * n_head * Sq floats) taken
+// from a fixed array in the library's device image instead of a caller buffer.  Every GPU the library runs on holds its
+// own copy of the array at its own address until the process ends; the address is looked up once per device, with that
+// device current, on the first call there.  All calls on one GPU share the array: calls that overlap (different streams)
+// race.  Nothing in the array has to start at zero (the dQ pass writes every word the dK/dV pass reads).
+constexpr int64_t STATIC_SCRATCH_FLOATS = 2ll << 20;  // 8 MiB
+static __device__ __align__(256) float scratch[STATIC_SCRATCH_FLOATS];
+
+static int static_scratch_ptr(float** out) {
+	constexpr int MAXDEV = 64;
+	static float* ptr[MAXDEV] = {nullptr};
+	static std::mutex mu;
+	int dev = 0;
+	hipError_t e = hipGetDevice(&dev);
+	if (e != hipSuccess) return VITK_ERR_HIP - (int)e;
+	if (dev < 0 || dev >= MAXDEV) return VITK_ERR_UNSUPPORTED;
+	std::lock_guard<std::mutex> lock(mu);
+	if (ptr[dev] == nullptr) {
+		float* p = nullptr;
+		e = hipGetSymbolAddress((void**)&p, HIP_SYMBOL(scratch));  // `scratch` itself is only a host-side handle, never a device address
+		if (e != hipSuccess) return VITK_ERR_HIP - (int)e;
+		if (p == nullptr) return VITK_ERR_NULL;
+		ptr[dev] = p;
+	}
+	*out = ptr[dev];
+	return VITK_OK;
+}
+
+extern "C" int vitk_attention_bwd_noalloc(const void* dout, const void* q, const void* k, const void* v, const void* out, const float* lse, void* dq,
+	void* dk, void* dv, int64_t B, int64_t n_head, int64_t Sq, int64_t Skv, int64_t dh, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
+	int64_t lddq, int64_t lddk, int64_t lddv, float scale, float dropout_p, uint64_t seed, int dtype, void* stream) {
+	VITK_REQUIRE(B > 0 && n_head > 0 && Sq > 0, VITK_ERR_SHAPE);
+	VITK_REQUIRE(B < (1ll << 31) && n_head < (1ll << 31) && Sq < (1ll << 31), VITK_ERR_SHAPE);
+	if (2 * B * n_head * Sq > STATIC_SCRATCH_FLOATS) return VITK_ERR_SCRATCH;
+	float* p = nullptr;
+	const int rc = static_scratch_ptr(&p);
+	if (rc != VITK_OK) return rc;
+	return vitk_attention_bwd_dropout(dout, q, k, v, out, lse, dq, dk, dv, B, n_head, Sq, Skv, dh, ldq, ldk, ldv, ldo, lddq, lddk, lddv, scale, dropout_p, seed, p,
 		dtype, stream);
 }

@@ -11,6 +11,7 @@ extern "C" const char* vitk_strerror(int status) {
 		case VITK_ERR_ALIGN: return "vitk: pointer or leading dimension is not aligned as required";
 		case VITK_ERR_NULL: return "vitk: a required pointer is null";
 		case VITK_ERR_UNSUPPORTED: return "vitk: unsupported option combination";
+		case VITK_ERR_SCRATCH: return "vitk: the problem needs more scratch than the library's fixed buffer holds (use the entry point that takes a caller buffer)";
 		default: break;
 	}
 	if (status <= VITK_ERR_HIP) return hipGetErrorString((hipError_t)(VITK_ERR_HIP - status));
