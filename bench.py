@@ -33,6 +33,9 @@ CONFIGS = {
 # SiLU, RMSNorm) on 32x32 inputs with 10 classes
 CVT = dict(chw=(3, 32, 32), out_d=10, batch=256, use_layer_scale=False, activation="silu",
 	s1=(7, 4, 2, 64, 1, 1, 4.0, 3, 1, 1), s2=(3, 2, 1, 192, 2, 3, 4.0, 3, 2, 1), s3=(3, 2, 1, 384, 10, 6, 4.0, 3, 2, 1))
+# BASELINE config 2: DeiT-style distillation of a ViT-Tiny student (with distillation token and head) from a frozen
+# CIFAR ResNet-20 teacher (deit_trainer.py:23-52, main.py:106-109 there), alpha 0.5, tau 1, batch 512
+DEIT = dict(CONFIGS["vit_tiny"], batch=512, alpha=0.5, tau=1.0)
 PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak of one MI355X
 
 
@@ -141,7 +144,7 @@ def main():
 	ap.add_argument("--warmup", type=int, default=3)
 	ap.add_argument("--graph", action="store_true", help="capture the training step into a HIP graph and replay it (single GPU)")
 	ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the config's)")
-	ap.add_argument("--config", default="vit_b16", choices=sorted(CONFIGS) + ["cvt"])
+	ap.add_argument("--config", default="vit_b16", choices=sorted(CONFIGS) + ["cvt", "deit_tiny"])
 	ap.add_argument("--dropout", type=float, default=0.0, help="config.dropout (attention-probability, branch and feed-forward dropouts)")
 	ap.add_argument("--no-cpu-baseline", action="store_true")
 	ap.add_argument("--no-kernel-timing", action="store_true")
@@ -168,12 +171,26 @@ def main():
 	from vit_amd.models import ViT
 
 	is_cvt = args.config == "cvt"
-	c = CVT if is_cvt else CONFIGS[args.config]
+	is_deit = args.config == "deit_tiny"
+	c = CVT if is_cvt else (DEIT if is_deit else CONFIGS[args.config])
 	batch = args.batch or c["batch"]
 	torch.manual_seed(0)
 	if is_cvt:
 		from vit_amd.models import CvT
 		model = CvT(make_cvt_config(args.dropout)).to(dev)
+	elif is_deit:
+		from vit_amd.models import DeiTViT
+		from vit_amd.models.teacher import frozen_teacher
+		model = DeiTViT(make_config(c, args.dropout)).to(dev)
+		# the teacher's weights: the reference's resnet20_cifar10 state_dict as recorded in the golden fixture (trained fc kept)
+		tsd, tsrc = None, "random init"
+		gpath = os.path.join(ROOT, "tests", "golden", "resnet20_teacher.npz")
+		if os.path.exists(gpath):
+			import numpy as np
+			z = np.load(gpath, allow_pickle=False)
+			tsd = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd/")}
+			tsrc = "reference resnet20_cifar10 weights (tests/golden/resnet20_teacher.npz)"
+		teacher = frozen_teacher(20, c["out_d"], tsd).to(dev).to(memory_format=torch.channels_last)
 	else:
 		model = ViT(make_config(c, args.dropout)).to(dev)
 	trainer = dp.Trainer(model, lr=args.lr, weight_decay=0.05)
@@ -181,11 +198,18 @@ def main():
 	x = torch.randn(batch, *c["chw"], generator=g).to(dev)
 	y = torch.randint(0, c["out_d"], (batch,), generator=g).to(dev)
 
+	def loss_of(xi, yi):
+		with torch.autocast("cuda", dtype=torch.bfloat16):
+			if is_deit:  # teacher forward under no_grad on stock PyTorch-ROCm, then the fused two-head loss
+				with torch.no_grad():
+					t_logits = teacher(xi.contiguous(memory_format=torch.channels_last))
+				cls, dist_ = model(xi)
+				return ops.deit_dual_loss(cls, dist_, yi, t_logits, alpha=c["alpha"], tau=c["tau"])
+			return ops.cross_entropy(model(xi), yi)
+
 	def step():
 		trainer.zero_grad()
-		with torch.autocast("cuda", dtype=torch.bfloat16):
-			logits = model(x)
-			loss = ops.cross_entropy(logits, y)
+		loss = loss_of(x, y)
 		loss.backward()
 		trainer.step()
 		return loss
@@ -200,10 +224,7 @@ def main():
 		# the whole step as one HIP graph launch (single process): for launch-bound configurations (ViT-Tiny)
 		assert world == 1, "--graph is single-GPU"
 
-		def loss_fn(xi, yi):
-			with torch.autocast("cuda", dtype=torch.bfloat16):
-				return ops.cross_entropy(model(xi), yi)
-		graphed = dp.GraphedStep(trainer, loss_fn, [x, y], warmup=max(args.warmup, 3))
+		graphed = dp.GraphedStep(trainer, loss_of, [x, y], warmup=max(args.warmup, 3))
 
 		def step():
 			return graphed(x, y)
@@ -228,7 +249,15 @@ def main():
 	first_loss = first.item() if first is not None else None
 	assert final_loss == final_loss, "loss is NaN"
 
-	if rank == 0 and is_cvt:
+	if rank == 0 and is_deit:
+		print(json.dumps({"metric": "train images/sec (node) DeiT-Tiny distillation 32x32 bf16", "value": round(batch * world * args.steps / elapsed, 2), "unit": "images/sec",
+			"n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True,
+			"scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+			"config": {"workload": "deit_tiny: ViT-Tiny/4 student with distillation token + head (d192/h3/L12/ff768, 66 tokens) distilled from a frozen CIFAR ResNet-20 "
+				f"teacher ({tsrc}; stock PyTorch-ROCm, no_grad), alpha {c['alpha']}, tau {c['tau']}, teacher fwd + student fwd + fused two-head loss + bwd + AdamW",
+				"global_batch": batch * world, "per_gpu_batch": batch, "parallelism": f"dp{world}", "hip_graph": bool(args.graph), "dropout": args.dropout},
+			"first_loss": None if first_loss is None else round(first_loss, 4), "final_loss": round(final_loss, 4), "lr": args.lr}), flush=True)
+	elif rank == 0 and is_cvt:
 		# secondary configuration (BASELINE config 3): throughput only, no FLOP model / roofline for it
 		print(json.dumps({"metric": "train images/sec (node) CvT-13 geometry 32x32 bf16", "value": round(batch * world * args.steps / elapsed, 2), "unit": "images/sec",
 			"n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True,

@@ -74,8 +74,9 @@ int vitk_version(void);
  * im2col-free A operand: with patch_grid > 0, A is an NCHW image batch [*, img_c, img_hw, img_hw]
  * and A(m,k) = image[m / P2][c][py*p + i][px*p + j], P2 = patch_grid^2, p = img_hw / patch_grid,
  * (py,px) = divmod(m % P2, patch_grid), (c,i,j) = unravel(k, (img_c,p,p)).  With tokens_per_image > 0
- * output row m is stored at row m + m / tokens_per_image + 1 (one class-token row is left free in
- * front of every image) and pos[(1 + m % tokens_per_image) * N + n] is added to v.
+ * output row m is stored at row m + (m / tokens_per_image + 1) * L and pos[(L + m % tokens_per_image) * N + n] is added to
+ * v, where L = max(lead_rows, 1) rows are left free in front of every image: the class-token row of models/vit.py:49, and
+ * with lead_rows = 2 a second learned (distillation) token row of a DeiT-style student.
  *
  * in_dtype is the dtype of A, B and aux; out_dtype of C and out2.  bias, gamma and pos are float32.
  * The bf16 MFMA path needs K % 8 == 0, 16-byte aligned A/B and leading dimensions that are
@@ -95,10 +96,10 @@ typedef struct vitk_gemm_desc {
 	int32_t patch_grid;        /* 0 = A is a plain matrix */
 	int32_t img_c, img_hw;
 	int32_t tokens_per_image;  /* 0 = no row remap / no pos add */
-	int32_t reserved;
+	int32_t lead_rows;         /* free token rows in front of every image when tokens_per_image > 0; 0 and 1 both mean one */
 	const float* bias;         /* [N] or null */
 	const float* gamma;        /* [N] or null (VITK_EPI_RESIDUAL) */
-	const float* pos;          /* [(tokens_per_image+1), N] or null */
+	const float* pos;          /* [(tokens_per_image + max(lead_rows, 1)), N] or null */
 	const void* aux;           /* [M, ld_aux] residual or pre-activation */
 	int64_t ld_aux;
 	void* out2;                /* [M, ld_out2] optional second output */
@@ -252,6 +253,8 @@ int vitk_patchify(const void* images, void* patches, int64_t B, int64_t C, int64
 int vitk_unpatchify(const void* patches, void* images, int64_t B, int64_t C, int64_t HW, int64_t n_patch, int dtype, void* stream);
 /* Copy rows [1, tokens) of every image of x[B, tokens, d] into a dense [B*(tokens-1), d] matrix. */
 int vitk_drop_cls_rows(const void* x, void* out, int64_t B, int64_t tokens, int64_t d, int dtype, void* stream);
+/* The same for `lead` leading rows per image (class + distillation token): rows [lead, tokens) -> [B*(tokens-lead), d]. */
+int vitk_drop_lead_rows(const void* x, void* out, int64_t B, int64_t tokens, int64_t d, int64_t lead, int dtype, void* stream);
 /* Token mean pool x[B, S, d] -> y[B, d] and its backward (models/cvt.py:105). */
 int vitk_mean_pool_fwd(const void* x, void* y, int64_t B, int64_t S, int64_t d, int dtype, void* stream);
 int vitk_mean_pool_bwd(const void* dy, void* dx, int64_t B, int64_t S, int64_t d, int dtype, void* stream);
@@ -266,6 +269,19 @@ int vitk_mean_pool_bwd(const void* dy, void* dx, int64_t B, int64_t S, int64_t d
  */
 int vitk_ce_kd_loss(const void* logits, const int64_t* labels, const void* teacher, float* loss, void* dlogits,
 	int64_t B, int64_t C, float label_smoothing, float alpha, float tau, int dtype, void* stream);
+
+/* Classifier and distillation heads of a DeiT-style student in one launch (the classifier of models/vit.py:63-65 applied to
+ * token row 0, and a second Linear applied to token row 1, the distillation token; deit_trainer.py:23-52 consumes the
+ * pair): logits_cls[b, c] = x[b, 0, :] . w_cls[c, :] + b_cls[c],  logits_dist[b, c] = x[b, 1, :] . w_dist[c, :] + b_dist[c].
+ * x [B, tokens, d] and the weights [C, d] in `dtype`, biases float32 (nullable), logits [B, C] in `dtype`.  Bandwidth-bound:
+ * one wavefront per (head, class), the weight row in registers, lane-strided dot products reduced by shuffles. */
+int vitk_dual_head_fwd(const void* x, const void* w_cls, const float* b_cls, const void* w_dist, const float* b_dist,
+	void* logits_cls, void* logits_dist, int64_t B, int64_t tokens, int64_t d, int64_t C, int dtype, void* stream);
+/* DeiT loss with a distillation head: (1-alpha) * CE(logits_cls, y; label_smoothing) + alpha * tau^2 *
+ * KL(softmax(teacher/tau) || softmax(logits_dist/tau)) / B  (deit_trainer.py:30-45 with the soft term moved to the second
+ * head).  Writes loss[0] (the caller zeroes it) and both gradients. */
+int vitk_deit_dual_loss(const void* logits_cls, const void* logits_dist, const int64_t* labels, const void* teacher, float* loss,
+	void* dlogits_cls, void* dlogits_dist, int64_t B, int64_t C, float label_smoothing, float alpha, float tau, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Fused AdamW over one flat float32 parameter buffer (torch.optim.AdamW semantics, main.py:100):

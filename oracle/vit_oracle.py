@@ -439,6 +439,32 @@ def vit_fwd(images, sd, n_patch, n_block, n_head, norm="layernorm", activation="
 	return linear_fwd(x[:, 0], sd["mlp.weight"], sd["mlp.bias"])
 
 
+def deit_vit_fwd(images, sd, n_patch, n_block, n_head, norm="layernorm", activation="gelu"):
+	"""The ViT of models/vit.py:43-69 with a second learned token (`dist_token`, row 1) and a second head (`dist_head`)
+	that reads it: the student shape DeiT-style distillation uses.  PARITY UNPINNED for the token itself (the reference
+	has no such model; an old trainer snapshot, _single_file.py:909-910, only accepts the output pair); every operation in
+	here is one the golden-pinned vit_fwd uses.  Returns (class logits, distillation logits)."""
+	b = images.shape[0]
+	tok = linear_fwd(patchify(images, n_patch), sd["linear_mapper.weight"], sd["linear_mapper.bias"])
+	cls = sd["class_token"].unsqueeze(0).expand(b, -1, -1)
+	dist = sd["dist_token"].unsqueeze(0).expand(b, -1, -1)
+	x = torch.cat([cls, dist, tok], 1) + sd["pos_embed"]
+	for i in range(n_block):
+		x = vit_block_fwd(x, sd, f"blocks.{i}.", n_head, norm, activation)
+	return linear_fwd(x[:, 0], sd["mlp.weight"], sd["mlp.bias"]), linear_fwd(x[:, 1], sd["dist_head.weight"], sd["dist_head.bias"])
+
+
+def deit_dual_loss_fwd(cls_logits, dist_logits, y, teacher, alpha=0.5, tau=1.0, label_smoothing=0.0):
+	"""The two terms of deit_trainer.py:30-45 on two heads: hard-label cross entropy on the class head, the soft
+	(teacher) term on the distillation head.  With cls_logits is dist_logits this is deit_loss_fwd, which the reference's
+	DeiTTrainer.compute_loss golden pins."""
+	base = cross_entropy_fwd(cls_logits, y, label_smoothing)
+	ls = torch.log_softmax(dist_logits.float() / tau, 1)
+	lt = torch.log_softmax(teacher.float() / tau, 1)
+	kl = (torch.exp(lt) * (lt - ls)).sum() / dist_logits.shape[0]
+	return (1 - alpha) * base + alpha * kl * (tau * tau)
+
+
 def conv_embedding_fwd(x, sd, prefix, stride, padding, training=True):
 	"""layers/embeddings.py:24-28: conv(bias=False) -> BatchNorm2d -> 'b c h w -> b (h w) c'."""
 	y = conv2d_fwd(x, sd[prefix + "conv.weight"], stride, padding)

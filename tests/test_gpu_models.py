@@ -463,3 +463,50 @@ def test_gradient_sinks_match_autograd(gpu, cfg):
 	for n in ref:
 		assert relerr(got[n], ref[n].cpu().double()) < 1e-4, n
 	assert len(arrivals) > 0 and max(arrivals.count(i) for i in set(arrivals)) == 2  # once per backward
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_deit_student_with_distillation_token(gpu, dtype):
+	"""The build-side DeiT student (second learned token + second head, both heads from one bandwidth-bound launch, the
+	two-head distillation loss as one fused call) against the oracle's restatement: both logits, the loss and every
+	parameter gradient.  The token has no counterpart in the reference (parity unpinned); the loss formula is pinned
+	through deit_loss.npz on the CPU."""
+	from oracle import vit_oracle as O
+	from vit_amd import ops
+	from vit_amd.layers import MHA
+	from vit_amd.models import DeiTViT
+
+	class Cfg:
+		attention = MHA
+		norm = nn.LayerNorm
+		activation = "gelu"
+		use_layer_scale = False
+		use_qk_norm = False
+		dropout = 0.0
+		d_model, n_head, n_block, n_patch, d_ff, out_d, chw = 192, 3, 3, 8, 768, 10, (3, 32, 32)
+	ops.clear_grad_sinks()
+	torch.manual_seed(3)
+	model = DeiTViT(Cfg()).to(gpu).train()
+	g = torch.Generator().manual_seed(8)
+	x = torch.randn(16, 3, 32, 32, generator=g)
+	y = torch.randint(0, 10, (16,), generator=g)
+	teacher = torch.randn(16, 10, generator=g) * 2
+	xg = x.to(gpu).requires_grad_(True)
+	with torch.autocast("cuda", dtype=torch.bfloat16, enabled=dtype == torch.bfloat16):
+		cls, dist = model(xg)
+		loss = ops.deit_dual_loss(cls.float(), dist.float(), y.to(gpu), teacher.to(gpu), alpha=0.3, tau=3.0, label_smoothing=0.1)
+	loss.backward()
+	sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
+	leaf = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+	xc = x.clone().requires_grad_(True)
+	wc, wd = O.deit_vit_fwd(xc, leaf, 8, 3, 3, "layernorm", "gelu")
+	wl = O.deit_dual_loss_fwd(wc, wd, y, teacher, alpha=0.3, tau=3.0, label_smoothing=0.1)
+	wl.backward()
+	tol, gtol = TOL[dtype], GTOL[dtype]
+	assert cls.dtype == dtype and relerr(cls, wc) < tol and relerr(dist, wd) < tol and relerr(loss, wl) < tol
+	assert relerr(xg.grad, xc.grad) < gtol
+	for k, p in model.named_parameters():
+		assert p.grad is not None and relerr(p.grad, leaf[k].grad) < gtol, k
+	model.eval()
+	with torch.no_grad():
+		assert relerr(model(x.to(gpu)), 0.5 * (wc + wd)) < tol

@@ -184,3 +184,24 @@ def test_mbconv(case, mode):
 	assert relerr(x.grad, c["dx"]) < 2 * TOL
 	for kk, v in sub(c, "grad").items():
 		assert relerr(leaf[kk].grad, v) < 2 * TOL, kk
+
+
+def test_dual_head_loss_reduces_to_the_pinned_deit_loss():
+	"""The two-head distillation loss with both heads fed the same logits is the reference's DeiTTrainer.compute_loss
+	(pinned by deit_loss.npz); the distillation token itself has no reference counterpart (parity unpinned)."""
+	g, meta = load_golden("deit_loss")
+	for c, (alpha, tau, ls) in meta["cases"].items():
+		d = sub(g, c)
+		got = O.deit_dual_loss_fwd(d["student"], d["student"], d["y"], d["teacher"], alpha=alpha, tau=tau, label_smoothing=ls)
+		assert relerr(got, d["loss"]) < TOL, c
+
+
+def test_teacher_resnet20_matches_the_reference_teacher():
+	"""The build-side CIFAR ResNet-20 (stock PyTorch modules) loads the reference teacher's state_dict strictly and
+	reproduces its eval-mode logits (golden: the reference's models/resnet.py with its own checkpoint weights)."""
+	from vit_amd.models.teacher import frozen_teacher
+	g, meta = load_golden("resnet20_teacher")
+	m = frozen_teacher(meta["depth"], meta["num_classes"], sub(g, "sd"))
+	with torch.no_grad():
+		assert relerr(m(g["x"]), g["logits"]) < TOL
+	assert not any(p.requires_grad for p in m.parameters()) and not m.training

@@ -92,11 +92,30 @@ def mbconv_fixture(args):
 	save(args.out, "mbconv", arrays, {"kind": "mbconv", "cases": {k: list(v) for k, v in MBCONV_CASES.items()}})
 
 
+def teacher_fixture(args):
+	"""The distillation teacher (models/resnet.py:55-85 there) with the weights of the reference's own
+	checkpoints/resnet20_cifar10.pth (a bare state_dict, read with weights_only=True): state_dict, a seeded input batch and the
+	eval-mode logits."""
+	from models.resnet import resnet_cifar
+	sd = torch.load(os.path.join(args.reference, "checkpoints", "resnet20_cifar10.pth"), map_location="cpu", weights_only=True)
+	m = resnet_cifar(20, num_classes=10)
+	m.load_state_dict(sd, strict=True)
+	m.eval()
+	g = torch.Generator().manual_seed(2020)
+	x = torch.randn(8, 3, 32, 32, generator=g)
+	with torch.no_grad():
+		logits = m(x)
+	arrays = {"x": np_(x), "logits": np_(logits)}
+	for k, v in m.state_dict().items():
+		arrays["sd/" + k] = np_(v)
+	save(args.out, "resnet20_teacher", arrays, {"kind": "teacher", "depth": 20, "num_classes": 10, "weights": "checkpoints/resnet20_cifar10.pth"})
+
+
 def main():
 	ap = argparse.ArgumentParser()
 	ap.add_argument("--reference", default="/root/reference")
 	ap.add_argument("--out", default="tests/golden")
-	ap.add_argument("--only", default="", help="generate only this fixture (currently: mbconv)")
+	ap.add_argument("--only", default="", help="generate only this fixture (mbconv, teacher)")
 	args = ap.parse_args()
 	sys.path.insert(0, args.reference)
 	os.makedirs(args.out, exist_ok=True)
@@ -104,6 +123,9 @@ def main():
 
 	if args.only == "mbconv":
 		mbconv_fixture(args)
+		return
+	if args.only == "teacher":
+		teacher_fixture(args)
 		return
 	from config import ViTConfig, CvTConfig
 	from layers.attention import MHA, ConvAttention

@@ -30,7 +30,7 @@ class GemmDesc(ctypes.Structure):
 		("epilogue", c_int32), ("act", c_int32),
 		("accumulate", c_int32),
 		("patch_grid", c_int32), ("img_c", c_int32), ("img_hw", c_int32),
-		("tokens_per_image", c_int32), ("reserved", c_int32),
+		("tokens_per_image", c_int32), ("lead_rows", c_int32),
 		("bias", c_void_p), ("gamma", c_void_p), ("pos", c_void_p),
 		("aux", c_void_p), ("ld_aux", c_int64),
 		("out2", c_void_p), ("ld_out2", c_int64),
@@ -75,9 +75,12 @@ SIGNATURES = {
 	"vitk_patchify": [P, P, I64, I64, I64, I64, I, P],
 	"vitk_unpatchify": [P, P, I64, I64, I64, I64, I, P],
 	"vitk_drop_cls_rows": [P, P, I64, I64, I64, I, P],
+	"vitk_drop_lead_rows": [P, P, I64, I64, I64, I64, I, P],
 	"vitk_mean_pool_fwd": [P, P, I64, I64, I64, I, P],
 	"vitk_mean_pool_bwd": [P, P, I64, I64, I64, I, P],
 	"vitk_ce_kd_loss": [P, P, P, P, P, I64, I64, FL, FL, FL, I, P],
+	"vitk_dual_head_fwd": [P, P, P, P, P, P, P, I64, I64, I64, I64, I, P],
+	"vitk_deit_dual_loss": [P, P, P, P, P, P, P, I64, I64, FL, FL, FL, I, P],
 	"vitk_adamw": [P, P, P, P, P, P, I64, FL, FL, FL, FL, FL, I64, FL, P],
 	"vitk_adamw_device_step": [P, P, P, P, P, P, I64, FL, FL, FL, FL, FL, P, FL, P],
 	"vitk_adamw_device_hparams": [P, P, P, P, P, P, I64, P, P, FL, P],

@@ -235,12 +235,41 @@ __global__ __launch_bounds__(256) void patchify_kernel(const T* __restrict__ src
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void drop_cls_kernel(const T* __restrict__ x, T* __restrict__ out, int64_t B, int64_t tokens, int64_t d) {
-	const int64_t per = (tokens - 1) * d;
+__global__ __launch_bounds__(256) void drop_cls_kernel(const T* __restrict__ x, T* __restrict__ out, int64_t B, int64_t tokens, int64_t d, int64_t lead) {
+	const int64_t per = (tokens - lead) * d;
 	const int64_t n = B * per;
 	for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
 		const int64_t b = i / per, r = i - b * per;
-		out[i] = x[b * tokens * d + d + r];
+		out[i] = x[b * tokens * d + lead * d + r];
+	}
+}
+
+// Classifier + distillation head: blockIdx.y = head (token row 0 / 1), one wave per class.  The wave keeps its weight row
+// in registers (lane l holds elements l, l + 64, ...; up to 16 per lane, longer rows are re-read), walks the batch and
+// reduces each dot product with shuffles.
+template <typename T>
+__global__ __launch_bounds__(256) void dual_head_kernel(const T* __restrict__ x, const T* __restrict__ w0, const float* __restrict__ b0, const T* __restrict__ w1,
+	const float* __restrict__ b1, T* __restrict__ y0, T* __restrict__ y1, int64_t B, int64_t tokens, int d, int C) {
+	const int lane = threadIdx.x & 63;
+	const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+	if (c >= C) return;
+	const int head = blockIdx.y;
+	const T* w = (head ? w1 : w0) + (int64_t)c * d;
+	const float* bias = head ? b1 : b0;
+	T* y = head ? y1 : y0;
+	const float bv = bias ? bias[c] : 0.f;
+	float wr[16];
+#pragma unroll
+	for (int i = 0; i < 16; ++i) wr[i] = lane + 64 * i < d ? to_f32<T>(w[lane + 64 * i]) : 0.f;
+	for (int64_t b = 0; b < B; ++b) {
+		const T* xr = x + (b * tokens + head) * d;
+		float acc = 0.f;
+#pragma unroll
+		for (int i = 0; i < 16; ++i)
+			if (lane + 64 * i < d) acc = fmaf(to_f32<T>(xr[lane + 64 * i]), wr[i], acc);
+		for (int k = lane + 1024; k < d; k += 64) acc = fmaf(to_f32<T>(xr[k]), to_f32<T>(w[k]), acc);
+		acc = wave_sum(acc);
+		if (lane == 0) y[b * C + c] = from_f32<T>(acc + bv);
 	}
 }
 
@@ -268,7 +297,7 @@ __global__ __launch_bounds__(256) void mean_pool_bwd_kernel(const T* __restrict_
 // One wavefront per sample.
 template <typename T>
 __global__ __launch_bounds__(256) void ce_kd_kernel(const T* __restrict__ logits, const int64_t* __restrict__ labels, const T* __restrict__ teacher,
-	float* loss, T* __restrict__ dlogits, int64_t B, int C, float ls, float alpha, float tau) {
+	float* loss, T* __restrict__ dlogits, int64_t B, int C, float ls, float w_ce, float alpha, float tau) {
 	const int lane = threadIdx.x & 63;
 	const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
 	if (row >= B) return;
@@ -304,7 +333,6 @@ __global__ __launch_bounds__(256) void ce_kd_kernel(const T* __restrict__ logits
 	}
 	const int y = (int)labels[row];
 	const float invB = 1.f / (float)B;
-	const float w_ce = t ? (1.f - alpha) : 1.f;
 	float kl = 0.f;
 	for (int c = lane; c < C; c += 64) {
 		const float v = to_f32<T>(s[c]);
@@ -616,11 +644,49 @@ extern "C" int vitk_unpatchify(const void* patches, void* images, int64_t B, int
 	});
 }
 
+extern "C" int vitk_drop_lead_rows(const void* x, void* out, int64_t B, int64_t tokens, int64_t d, int64_t lead, int dtype, void* stream) {
+	VITK_REQUIRE(x && out, VITK_ERR_NULL);
+	VITK_REQUIRE(B > 0 && lead >= 1 && tokens > lead && d > 0, VITK_ERR_SHAPE);
+	DISPATCH_T(dtype, {
+		hipLaunchKernelGGL((drop_cls_kernel<T>), dim3(vitk_stream_grid(B * (tokens - lead) * d, 256)), dim3(256), 0, (hipStream_t)stream, (const T*)x, (T*)out, B, tokens, d, lead);
+		VITK_CHECK_LAUNCH();
+		return VITK_OK;
+	});
+}
+
+extern "C" int vitk_dual_head_fwd(const void* x, const void* w_cls, const float* b_cls, const void* w_dist, const float* b_dist, void* logits_cls, void* logits_dist,
+	int64_t B, int64_t tokens, int64_t d, int64_t C, int dtype, void* stream) {
+	VITK_REQUIRE(x && w_cls && w_dist && logits_cls && logits_dist, VITK_ERR_NULL);
+	VITK_REQUIRE(B > 0 && tokens >= 2 && d > 0 && C > 0 && d < (1ll << 31) && C < (1ll << 31), VITK_ERR_SHAPE);
+	DISPATCH_T(dtype, {
+		hipLaunchKernelGGL((dual_head_kernel<T>), dim3((unsigned)vitk_cdiv(C, 4), 2), dim3(256), 0, (hipStream_t)stream, (const T*)x, (const T*)w_cls, b_cls, (const T*)w_dist, b_dist,
+			(T*)logits_cls, (T*)logits_dist, B, tokens, (int)d, (int)C);
+		VITK_CHECK_LAUNCH();
+		return VITK_OK;
+	});
+}
+
+extern "C" int vitk_deit_dual_loss(const void* logits_cls, const void* logits_dist, const int64_t* labels, const void* teacher, float* loss, void* dlogits_cls,
+	void* dlogits_dist, int64_t B, int64_t C, float label_smoothing, float alpha, float tau, int dtype, void* stream) {
+	VITK_REQUIRE(logits_cls && logits_dist && labels && teacher && loss && dlogits_cls && dlogits_dist, VITK_ERR_NULL);
+	VITK_REQUIRE(B > 0 && C > 0 && C < (1ll << 31) && tau > 0.f, VITK_ERR_SHAPE);
+	DISPATCH_T(dtype, {
+		// class head: hard-label cross entropy weighted 1 - alpha; distillation head: the soft term weighted alpha
+		hipLaunchKernelGGL((ce_kd_kernel<T>), dim3((unsigned)vitk_cdiv(B, 4)), dim3(256), 0, (hipStream_t)stream, (const T*)logits_cls, labels, (const T*)nullptr, loss,
+			(T*)dlogits_cls, B, (int)C, label_smoothing, 1.f - alpha, 0.f, tau);
+		VITK_CHECK_LAUNCH();
+		hipLaunchKernelGGL((ce_kd_kernel<T>), dim3((unsigned)vitk_cdiv(B, 4)), dim3(256), 0, (hipStream_t)stream, (const T*)logits_dist, labels, (const T*)teacher, loss,
+			(T*)dlogits_dist, B, (int)C, 0.f, 0.f, alpha, tau);
+		VITK_CHECK_LAUNCH();
+		return VITK_OK;
+	});
+}
+
 extern "C" int vitk_drop_cls_rows(const void* x, void* out, int64_t B, int64_t tokens, int64_t d, int dtype, void* stream) {
 	VITK_REQUIRE(x && out, VITK_ERR_NULL);
 	VITK_REQUIRE(B > 0 && tokens > 1 && d > 0, VITK_ERR_SHAPE);
 	DISPATCH_T(dtype, {
-		hipLaunchKernelGGL((drop_cls_kernel<T>), dim3(vitk_stream_grid(B * (tokens - 1) * d, 256)), dim3(256), 0, (hipStream_t)stream, (const T*)x, (T*)out, B, tokens, d);
+		hipLaunchKernelGGL((drop_cls_kernel<T>), dim3(vitk_stream_grid(B * (tokens - 1) * d, 256)), dim3(256), 0, (hipStream_t)stream, (const T*)x, (T*)out, B, tokens, d, (int64_t)1);
 		VITK_CHECK_LAUNCH();
 		return VITK_OK;
 	});
@@ -654,7 +720,7 @@ extern "C" int vitk_ce_kd_loss(const void* logits, const int64_t* labels, const 
 	if (alpha == 0.f) teacher = nullptr;
 	DISPATCH_T(dtype, {
 		hipLaunchKernelGGL((ce_kd_kernel<T>), dim3((unsigned)vitk_cdiv(B, 4)), dim3(256), 0, (hipStream_t)stream, (const T*)logits, labels, (const T*)teacher, loss,
-			(T*)dlogits, B, (int)C, label_smoothing, alpha, tau);
+			(T*)dlogits, B, (int)C, label_smoothing, teacher ? 1.f - alpha : 1.f, alpha, tau);
 		VITK_CHECK_LAUNCH();
 		return VITK_OK;
 	});

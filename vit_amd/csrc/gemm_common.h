@@ -14,6 +14,7 @@ struct GemmDev {
 	int epilogue, act, accumulate;
 	int patch_grid, img_c, img_hw, patch_px;  // patch_px = img_hw / patch_grid
 	int tpi;                                  // tokens_per_image
+	int lead;                                 // free rows in front of every image (class token, distillation token), >= 1
 	const float* bias;
 	const float* gamma;
 	const float* pos;
@@ -36,6 +37,7 @@ static inline GemmDev make_gemm_dev(const vitk_gemm_desc& d) {
 	g.patch_grid = d.patch_grid; g.img_c = d.img_c; g.img_hw = d.img_hw;
 	g.patch_px = d.patch_grid > 0 ? d.img_hw / d.patch_grid : 0;
 	g.tpi = d.tokens_per_image;
+	g.lead = d.lead_rows > 1 ? d.lead_rows : 1;
 	g.bias = d.bias; g.gamma = d.gamma; g.pos = d.pos;
 	g.aux = d.aux; g.ld_aux = d.ld_aux; g.out2 = d.out2; g.ld_out2 = d.ld_out2;
 	g.drop_scale = 1.f;
@@ -64,7 +66,7 @@ __device__ __forceinline__ int64_t patch_offset(const GemmDev& g, int64_t m, int
 	return ((b * g.img_c + c) * hw + (py * p + i)) * (int64_t)hw + (px * p + j);
 }
 
-__device__ __forceinline__ int64_t out_row(const GemmDev& g, int64_t m) { return g.tpi > 0 ? m + m / g.tpi + 1 : m; }
+__device__ __forceinline__ int64_t out_row(const GemmDev& g, int64_t m) { return g.tpi > 0 ? m + (m / g.tpi + 1) * g.lead : m; }
 
 // Fused dropout: multipliers (0 or g.drop_scale) of the N consecutive elements (m, n0 .. n0 + N - 1); the mask is
 // indexed by the logical element m * g.N + n.  Call only when g.drop[0].thr16 != 0.
@@ -102,7 +104,7 @@ __device__ __forceinline__ void epi_store1(const GemmDev& g, int64_t m, int64_t 
 	const int act = ACT >= 0 ? ACT : g.act;
 	float v = acc;
 	if (g.bias) v += g.bias[n];
-	if (g.tpi > 0 && g.pos) v += g.pos[(1 + m % g.tpi) * g.N + n];
+	if (g.tpi > 0 && g.pos) v += g.pos[(g.lead + m % g.tpi) * g.N + n];
 	const int64_t r = out_row(g, m);
 	// fused dropout: multiplier of the masked quantity (the mask is indexed by the logical element m * N + n)
 	float keep = 1.f;
@@ -140,7 +142,7 @@ __device__ __forceinline__ void epi_store4(const GemmDev& g, int64_t m, int64_t 
 	}
 	if (g.tpi > 0 && g.pos) {
 		float p[4];
-		load_vec<float, 4>(g.pos + (1 + m % g.tpi) * g.N + n0, p);
+		load_vec<float, 4>(g.pos + (g.lead + m % g.tpi) * g.N + n0, p);
 #pragma unroll
 		for (int j = 0; j < 4; ++j) v[j] += p[j];
 	}

@@ -1,2 +1,3 @@
 from .vit import ViT  # noqa: F401
 from .cvt import CvT  # noqa: F401
+from .deit import DeiTViT  # noqa: F401

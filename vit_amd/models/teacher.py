@@ -1,0 +1,65 @@
+"""The CIFAR ResNet-20 / -32 teacher of the distillation configuration, on stock PyTorch-ROCm modules (MIOpen): it runs
+frozen, in eval mode and under no_grad, and only its logits enter the hot path (the fused distillation loss), so it is not
+part of the kernel library.  Architecture and parameter names follow the reference's teacher (models/resnet.py:21-85 there:
+3 stages of 3x3 basic blocks at 16 / 32 / 64 channels, parameter-free "option A" shortcuts, global average pool, `fc`),
+so the bare state_dict of its checkpoints/resnet20_cifar10.pth loads with strict=True (load it with
+torch.load(..., weights_only=True))."""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+class _Block(nn.Module):
+	def __init__(self, cin, cout, stride):
+		super().__init__()
+		self.conv1 = nn.Conv2d(cin, cout, 3, stride, 1, bias=False)
+		self.bn1 = nn.BatchNorm2d(cout)
+		self.conv2 = nn.Conv2d(cout, cout, 3, 1, 1, bias=False)
+		self.bn2 = nn.BatchNorm2d(cout)
+		self.pad = (cout - cin) // 2 if (stride != 1 or cin != cout) else None
+		self.stride = stride
+
+	def forward(self, x):
+		y = F.relu(self.bn1(self.conv1(x)))
+		y = self.bn2(self.conv2(y))
+		if self.pad is not None:  # option A: subsample, zero-pad the new channels
+			x = F.pad(x[:, :, ::self.stride, ::self.stride], (0, 0, 0, 0, self.pad, self.pad))
+		return F.relu(y + x)
+
+
+class CifarResNet(nn.Module):
+	def __init__(self, depth=20, num_classes=10):
+		super().__init__()
+		if depth not in (20, 32):
+			raise ValueError(f"Invalid ResNet depth for CIFAR: {depth}")
+		n = (depth - 2) // 6
+		self.conv1 = nn.Conv2d(3, 16, 3, 1, 1, bias=False)
+		self.bn1 = nn.BatchNorm2d(16)
+		cin, stages = 16, []
+		for cout, stride in ((16, 1), (32, 2), (64, 2)):
+			blocks = []
+			for i in range(n):
+				blocks.append(_Block(cin, cout, stride if i == 0 else 1))
+				cin = cout
+			stages.append(nn.Sequential(*blocks))
+		self.layer1, self.layer2, self.layer3 = stages
+		self.fc = nn.Linear(64, num_classes)
+		for m in self.modules():
+			if isinstance(m, (nn.Conv2d, nn.Linear)):
+				nn.init.kaiming_normal_(m.weight)
+
+	def forward(self, x):
+		x = F.relu(self.bn1(self.conv1(x)))
+		x = self.layer3(self.layer2(self.layer1(x)))
+		return self.fc(x.mean((2, 3)))
+
+
+def frozen_teacher(depth=20, num_classes=10, state_dict=None):
+	"""Teacher as DeiTTrainer holds it (deit_trainer.py:15-18 there): eval mode, no gradients."""
+	m = CifarResNet(depth, num_classes)
+	if state_dict is not None:
+		m.load_state_dict(state_dict, strict=True)
+	m.eval()
+	for p in m.parameters():
+		p.requires_grad_(False)
+	return m

@@ -245,7 +245,7 @@ def gemm_workspace(device):
 
 
 def gemm(A, B, C, M, N, K, lda, ldb, ldc, a_layout=L.K_MAJOR, b_layout=L.K_MAJOR, bias=None, epilogue=L.EPI_NONE, act=L.ACT_NONE,
-		aux=None, ld_aux=0, out2=None, ld_out2=0, gamma=None, accumulate=False, patch=None, tokens_per_image=0, pos=None, a_colsum=None, workspace=True, drop=()):
+		aux=None, ld_aux=0, out2=None, ld_out2=0, gamma=None, accumulate=False, patch=None, tokens_per_image=0, pos=None, a_colsum=None, workspace=True, drop=(), lead_rows=0):
 	"""C[M,N] (+)= epilogue(sum_k A(m,k) B(n,k)); see include/vitk.h for the operand layouts.  drop: up to two (p, seed)
 	dropouts fused into the epilogue (entries with p == 0 are ignored)."""
 	L.require_gpu(A, B, C)
@@ -260,6 +260,7 @@ def gemm(A, B, C, M, N, K, lda, ldb, ldc, a_layout=L.K_MAJOR, b_layout=L.K_MAJOR
 	if patch is not None:
 		d.patch_grid, d.img_c, d.img_hw = patch
 	d.tokens_per_image = tokens_per_image
+	d.lead_rows = lead_rows
 	d.bias, d.gamma, d.pos = L.ptr(bias), L.ptr(gamma), L.ptr(pos)
 	d.aux, d.ld_aux = L.ptr(aux), ld_aux
 	d.out2, d.ld_out2 = L.ptr(out2), ld_out2
@@ -731,40 +732,46 @@ class ViTBlockFn(torch.autograd.Function):
 
 
 class PatchEmbedFn(torch.autograd.Function):
-	"""images -> tokens [B, P*P + 1, d]: im2col-free patch GEMM + bias + pos_embed in the epilogue, class-token row
-	written by a small kernel (models/vit.py:46-52)."""
+	"""images -> tokens [B, L + P*P, d]: im2col-free patch GEMM + bias + pos_embed in the epilogue, the L leading learned
+	token rows written by a small kernel (models/vit.py:46-52: L = 1, the class token; with `dist_token` L = 2, the
+	class token and a distillation token, the student of a DeiT-style distillation)."""
 
 	@staticmethod
-	def forward(ctx, images, w, b, class_token, pos_embed, n_patch):
+	def forward(ctx, images, w, b, class_token, pos_embed, n_patch, dist_token=None):
 		L.require_gpu(images, w)
 		dt = compute_dtype(images)
 		Bn, C, H, W = images.shape
 		assert H == W, "Patchify method is implemented for square images only"
 		img = cast(images, dt)
 		P2 = n_patch * n_patch
+		lead = 1 if dist_token is None else 2
 		d = w.shape[0]
 		K = w.shape[1]
-		x = torch.empty((Bn, P2 + 1, d), dtype=dt, device=images.device)
-		pos = f32(pos_embed).reshape(P2 + 1, d)
-		gemm(img, weight_as(w, dt), x, Bn * P2, d, K, K, K, d, bias=f32(b), patch=(n_patch, C, H), tokens_per_image=P2, pos=pos)
-		L.check(L.load().vitk_cls_rows(L.ptr(x), L.ptr(f32(class_token)), L.ptr(pos), Bn, P2 + 1, d, L.dtype_code(dt), L.stream()))
+		x = torch.empty((Bn, P2 + lead, d), dtype=dt, device=images.device)
+		pos = f32(pos_embed).reshape(P2 + lead, d)
+		gemm(img, weight_as(w, dt), x, Bn * P2, d, K, K, K, d, bias=f32(b), patch=(n_patch, C, H), tokens_per_image=P2, pos=pos, lead_rows=lead)
+		lib, dtc = L.load(), L.dtype_code(dt)
+		L.check(lib.vitk_cls_rows(L.ptr(x), L.ptr(f32(class_token)), L.ptr(pos), Bn, P2 + lead, d, dtc, L.stream()))
+		if dist_token is not None:  # row 1 of every image: the same kernel on the buffers shifted by one row
+			L.check(lib.vitk_cls_rows(x.data_ptr() + d * x.element_size(), L.ptr(f32(dist_token)), pos.data_ptr() + 4 * d, Bn, P2 + lead, d, dtc, L.stream()))
 		ctx.save_for_backward(img, w)
-		ctx.meta = (images.shape, images.dtype, b, class_token, pos_embed, n_patch, dt)
+		ctx.meta = (images.shape, images.dtype, b, class_token, pos_embed, n_patch, dt, dist_token)
 		return x
 
 	@staticmethod
 	def backward(ctx, dx):
 		img, w = ctx.saved_tensors
-		(Bn, C, H, W), idtype, b, class_token, pos_embed, n_patch, dt = ctx.meta
+		(Bn, C, H, W), idtype, b, class_token, pos_embed, n_patch, dt, dist_token = ctx.meta
 		lib = L.load()
 		P2 = n_patch * n_patch
+		lead = 1 if dist_token is None else 2
 		d, K = w.shape
 		dx = cast(dx, dt)
 		dtc = L.dtype_code(dt)
-		dpos = torch.empty((P2 + 1, d), dtype=torch.float32, device=dx.device)
-		L.check(lib.vitk_batch_sum(L.ptr(dx), L.ptr(dpos), Bn, P2 + 1, d, 0, dtc, L.stream()))
+		dpos = torch.empty((P2 + lead, d), dtype=torch.float32, device=dx.device)
+		L.check(lib.vitk_batch_sum(L.ptr(dx), L.ptr(dpos), Bn, P2 + lead, d, 0, dtc, L.stream()))
 		dtok = torch.empty((Bn * P2, d), dtype=dt, device=dx.device)
-		L.check(lib.vitk_drop_cls_rows(L.ptr(dx), L.ptr(dtok), Bn, P2 + 1, d, dtc, L.stream()))
+		L.check(lib.vitk_drop_lead_rows(L.ptr(dx), L.ptr(dtok), Bn, P2 + lead, d, lead, dtc, L.stream()))
 		patches = torch.empty((Bn * P2, K), dtype=dt, device=dx.device)
 		L.check(lib.vitk_patchify(L.ptr(img), L.ptr(patches), Bn, C, H, n_patch, dtc, L.stream()))
 		dw, db = linear_wgrad(dtok, patches, bias_grad=True)
@@ -776,7 +783,48 @@ class PatchEmbedFn(torch.autograd.Function):
 			if dimg.dtype != idtype:
 				dimg = cast(dimg, idtype)
 		dcls = dpos[0:1].clone()
-		return dimg, grad_as(dw, w), grad_as(db, b), grad_as(dcls.reshape(class_token.shape), class_token), grad_as(dpos.reshape(pos_embed.shape), pos_embed), None
+		ddist = None if dist_token is None else grad_as(dpos[1:2].clone().reshape(dist_token.shape), dist_token)
+		return (dimg, grad_as(dw, w), grad_as(db, b), grad_as(dcls.reshape(class_token.shape), class_token), grad_as(dpos.reshape(pos_embed.shape), pos_embed), None,
+			ddist)
+
+
+class DualHeadFn(torch.autograd.Function):
+	"""(x[:, 0] @ w_cls.T + b_cls, x[:, 1] @ w_dist.T + b_dist): classifier on the class-token row (models/vit.py:63-65) and a
+	second head on the distillation-token row, both by ONE bandwidth-bound launch that reads the two rows in place."""
+
+	@staticmethod
+	def forward(ctx, x, w_cls, b_cls, w_dist, b_dist):
+		L.require_gpu(x, w_cls, w_dist)
+		dt = compute_dtype(x)
+		xc = cast(x, dt)
+		Bn, S, d = xc.shape
+		C = w_cls.shape[0]
+		assert S >= 2 and w_dist.shape == w_cls.shape == (C, d)
+		y0 = torch.empty((Bn, C), dtype=dt, device=x.device)
+		y1 = torch.empty((Bn, C), dtype=dt, device=x.device)
+		L.check(L.load().vitk_dual_head_fwd(L.ptr(xc), L.ptr(weight_as(w_cls, dt)), L.ptr(f32(b_cls)), L.ptr(weight_as(w_dist, dt)), L.ptr(f32(b_dist)), L.ptr(y0),
+			L.ptr(y1), Bn, S, d, C, L.dtype_code(dt), L.stream()))
+		ctx.save_for_backward(xc, w_cls, w_dist)
+		ctx.meta = (x.dtype, b_cls, b_dist, dt)
+		return y0, y1
+
+	@staticmethod
+	def backward(ctx, dy0, dy1):
+		xc, w_cls, w_dist = ctx.saved_tensors
+		xdtype, b_cls, b_dist, dt = ctx.meta
+		Bn, S, d = xc.shape
+		rows = xc.reshape(Bn * S, d)
+		dx = torch.zeros((Bn, S, d), dtype=dt, device=xc.device) if ctx.needs_input_grad[0] else None
+		grads = []
+		for r, dy, w, b in ((0, dy0, w_cls, b_cls), (1, dy1, w_dist, b_dist)):
+			dyc = cast(dy, dt)
+			dw, db = linear_wgrad(dyc, rows[r::S], bias_grad=b is not None)
+			if dx is not None:
+				linear_dgrad(dyc, weight_as(w, dt), out=dx.reshape(Bn * S, d)[r::S])
+			grads += [grad_as(dw, w), grad_as(db, b)]
+		if dx is not None and dx.dtype != xdtype:
+			dx = cast(dx, xdtype)
+		return (dx, *grads)
 
 
 class ClsHeadFn(torch.autograd.Function):
@@ -834,6 +882,39 @@ class CeKdLossFn(torch.autograd.Function):
 	def backward(ctx, g):
 		(dlogits,) = ctx.saved_tensors
 		return dlogits * g.to(dlogits.dtype), None, None, None, None, None
+
+
+class DeitDualLossFn(torch.autograd.Function):
+	"""(1-alpha) * CE(logits_cls, y; label_smoothing) + alpha * tau^2 * KL(softmax(teacher/tau) || softmax(logits_dist/tau)),
+	batchmean: the loss of deit_trainer.py:30-45 with the soft term on the distillation head."""
+
+	@staticmethod
+	def forward(ctx, logits_cls, logits_dist, labels, teacher, label_smoothing, alpha, tau):
+		L.require_gpu(logits_cls, logits_dist, labels, teacher)
+		lc, ld = logits_cls.contiguous(), logits_dist.contiguous()
+		assert lc.dtype == ld.dtype and lc.shape == ld.shape
+		t = cast(teacher.detach(), lc.dtype)
+		Bn, C = lc.shape
+		loss = torch.zeros(1, dtype=torch.float32, device=lc.device)
+		dc, dd = torch.empty_like(lc), torch.empty_like(ld)
+		L.check(L.load().vitk_deit_dual_loss(L.ptr(lc), L.ptr(ld), L.ptr(labels.contiguous()), L.ptr(t), L.ptr(loss), L.ptr(dc), L.ptr(dd), Bn, C,
+			float(label_smoothing), float(alpha), float(tau), L.dtype_code(lc.dtype), L.stream()))
+		ctx.save_for_backward(dc, dd)
+		return loss[0]
+
+	@staticmethod
+	def backward(ctx, g):
+		dc, dd = ctx.saved_tensors
+		return scale_by(dc, g), scale_by(dd, g), None, None, None, None, None
+
+
+def scale_by(t, g):
+	"""t * g for the scalar upstream gradient g of a loss; g == 1 (loss.backward()) costs nothing."""
+	return t * g.to(t.dtype)
+
+
+def deit_dual_loss(logits_cls, logits_dist, labels, teacher, alpha=0.5, tau=1.0, label_smoothing=0.0):
+	return DeitDualLossFn.apply(logits_cls, logits_dist, labels, teacher, label_smoothing, alpha, tau)
 
 
 def cross_entropy(logits, labels, label_smoothing=0.0):
