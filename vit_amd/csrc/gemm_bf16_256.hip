@@ -1002,7 +1002,20 @@ int vitk_gemm_bf16_256(const vitk_gemm_desc& d, hipStream_t st, bool* colsum_don
 		hipError_t e = hipMemset2DAsync(d.C, (size_t)d.ldc * sizeof(float), 0, (size_t)d.N * sizeof(float), (size_t)d.M, st);
 		if (e != hipSuccess) return VITK_ERR_HIP - (int)e;
 	}
-	int rc = launch_variant(a, d, dim3((unsigned)(tiles * a.splits)), st);
+	int rc = VITK_ERR_UNSUPPORTED;
+	static const bool p8w = std::getenv("VITK_NO_P8W") == nullptr;  // A-B switch
+	if (p8w && a.partials != nullptr && d.a_layout == VITK_MN_MAJOR && d.b_layout == VITK_MN_MAJOR && d.out_dtype == VITK_F32 && (d.a_colsum == nullptr || a.cs_partials != nullptr)) {
+		WgradArgs w{};
+		w.g = a.g;
+		w.tiles_m = a.tiles_m;
+		w.tiles_n = a.tiles_n;
+		w.splits = a.splits;
+		w.k_per_split = a.k_per_split;
+		w.cs_partials = a.cs_partials;
+		w.partials = a.partials;
+		if (vitk_gemm_bf16_p8w_ok(w)) rc = vitk_gemm_bf16_p8w(w, st);
+	}
+	if (rc == VITK_ERR_UNSUPPORTED) rc = launch_variant(a, d, dim3((unsigned)(tiles * a.splits)), st);
 	if (rc == VITK_OK && a.partials != nullptr) {
 		hipLaunchKernelGGL(split_reduce_kernel, dim3(BM * BN / 4 / 256, (unsigned)tiles + 1), dim3(256), 0, st, a.partials, reinterpret_cast<float*>(d.C), d.M, d.N, d.ldc, a.tiles_n,
 			(int)tiles, a.splits, d.accumulate, a.vec4, a.cs_partials, d.a_colsum);

@@ -269,6 +269,221 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_p8_kernel(P8Args a) {
 	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the last (unused) DMA must not outlive the workgroup's LDS
 }
 
+// ---- weight gradients: dW[m, n] = sum over tokens k of dY[k, m] X[k, n] ----------------------------------------------------
+// Same pipeline with MN-major operands (A(m, k) = A[k * lda + m]): a half-tile is [64 k][128 columns] in 256-byte rows, staged
+// in pieces of 4 rows, fragments come out of it through the transposing read ds_read_b64_tr_b16 (two per fragment).  Bank
+// swizzle: the 32-byte unit index of a row is XORed with fk(k) = (k & 3) | ((k >> 3) & 1) << 2, which is distinct for the 8
+// rows one half-wave's transposing read touches.  One (tile, K slice) per workgroup, the float32 partial tile leaves in
+// accumulator order (one contiguous KiB per wave-instruction).
+__device__ __forceinline__ int fk(int k) { return (k & 3) | (((k >> 3) & 1) << 2); }
+
+__device__ __forceinline__ void lds_read_tr(s16x4& dst, uint32_t addr, int offset) {
+	asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(offset));
+}
+__device__ __forceinline__ bf16x8 join8(s16x4 lo, s16x4 hi) {
+	union {
+		s16x4 h[2];
+		bf16x8 v;
+	} u;
+	u.h[0] = lo;
+	u.h[1] = hi;
+	return u.v;
+}
+
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_p8w_kernel(WgradArgs a) {
+	extern __shared__ __attribute__((aligned(16))) char smem[];
+	const GemmDev& g = a.g;
+	const int tid = threadIdx.x, lane = tid & 63;
+	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+	const int wr = wave >> 2, wc = wave & 3;
+	// (tile, K slice) of this workgroup, K slice outermost: workgroups that share an XCD get neighbouring tiles of one slice
+	const int ntile = a.tiles_m * a.tiles_n;
+	const int nwg = ntile * a.splits;
+	int wg = blockIdx.x;
+	{
+		const int q = nwg >> 3, r = nwg & 7, xcd = wg & 7, idx = wg >> 3;
+		wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+	}
+	const int split = wg / ntile;
+	wg -= split * ntile;
+	constexpr int GM = 4;
+	const int per_group = GM * a.tiles_n;
+	const int group = wg / per_group;
+	const int first_m = group * GM;
+	const int gsz = min(a.tiles_m - first_m, GM);
+	const int tm = first_m + (wg % per_group) % gsz;
+	const int tn = (wg % per_group) / gsz;
+	const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
+	const int k_begin = split * a.k_per_split;
+	const int k_end = min((int)g.K, k_begin + a.k_per_split);
+	const int nt = (k_end - k_begin) / BK;  // >= 1
+
+	const bf16_t* A = reinterpret_cast<const bf16_t*>(g.A);
+	const bf16_t* B = reinterpret_cast<const bf16_t*>(g.B);
+	const uint32_t lds0 = lds_addr(smem);
+
+	// LDS-DMA: a piece is 4 k-rows x 256 bytes; lane l lands at row l >> 4, physical 16-byte chunk l & 15 and therefore
+	// fetches the logical chunk whose unit is (physical unit) ^ fk(row).  Rows of a piece: k = 4 * piece + (l >> 4) with piece =
+	// 2 * wave + j, so fk(k) = ((l >> 4) & 3) | (wave & 1) << 2 for both pieces of a wave: the lane offsets are loop invariant.
+	const int prow = lane >> 4, pchunk = lane & 15;
+	const int lchunk = ((((pchunk >> 1) ^ (prow | ((wave & 1) << 2))) << 1) | (pchunk & 1));  // logical chunk: 8 columns of the half-tile
+	// half-tile column 8 * lchunk -> tile column: A halves interleave 64-column blocks, B halves 32-column blocks
+	const int a_col = (lchunk >> 3) * 128 + 8 * (lchunk & 7);   // + h * 64
+	const int b_col = (lchunk >> 2) * 64 + 8 * (lchunk & 3);    // + h' * 32
+	const uint32_t a_voff = (uint32_t)(prow * (int)g.lda + a_col) * 2u;
+	const uint32_t b_voff = (uint32_t)(prow * (int)g.ldb + b_col) * 2u;
+	auto stage_half = [&](int buf, int which, int kstep) {
+		char* dst = smem + buf * STEP_BYTES + which * HALF_BYTES;
+		const int64_t k0 = k_begin + (int64_t)min(kstep, nt - 1) * BK;  // past the slice: fetch its last step again (nobody reads it)
+#pragma unroll
+		for (int j = 0; j < 2; ++j) {
+			const int p = 2 * wave + j;
+			const char* src;
+			if (which < 2) src = reinterpret_cast<const char*>(A + (k0 + 4 * p) * g.lda + m0 + which * 64) + a_voff;
+			else src = reinterpret_cast<const char*>(B + (k0 + 4 * p) * g.ldb + n0 + (which - 2) * 32) + b_voff;
+			__builtin_amdgcn_global_load_lds((gbl_void_p)src, (lds_void_p)(dst + p * 1024), 16, 0, 0);
+		}
+	};
+
+	// transposing fragment reads: lane (g4, q, p) = (lane >> 4, (lane >> 2) & 3, lane & 3) addresses k-row 8 g4 + q (+ 32 s, + 4 for
+	// the second read), columns 4 p .. 4 p + 3 of the fragment's 16; fragment f of a wave starts at 16-byte chunk 2 f + (p >> 1)
+	// of the wave's block, i.e. unit (block unit) ^ f: one address per operand, XOR f << 5 per fragment
+	const int g4 = lane >> 4, fq = (lane >> 2) & 3, fp = lane & 3;
+	const int frow = 8 * g4 + fq;
+	auto frag_addr = [&](int unit0) { return (uint32_t)(frow * 256 + ((((unit0 ^ fk(frow)) << 1) | (fp >> 1)) << 4) + ((fp & 1) << 3)); };
+	const uint32_t a_lane = frag_addr(wr * 4), b_lane = frag_addr(wc * 2);
+
+	f32x4 acc[8][4];
+#pragma unroll
+	for (int i = 0; i < 8; ++i)
+#pragma unroll
+		for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+	// prologue: all of K step 0, and A_0, B_0, B_1 of K step 1 (its A_1 goes out in phase A of step 0)
+	stage_half(0, 2, 0);
+	stage_half(0, 0, 0);
+	stage_half(0, 3, 0);
+	stage_half(0, 1, 0);
+	stage_half(1, 0, 1);
+	stage_half(1, 2, 1);
+	stage_half(1, 3, 1);
+	asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+	__builtin_amdgcn_s_barrier();
+
+	// column sums of A (the bias gradient): the tiles_n workgroups that share an A tile take turns per K step; thread (c, r) =
+	// (tid & 255, tid >> 8) adds up k-rows 32 r .. 32 r + 31 of tile column c, which lives in half-tile (c >> 6) & 1 =
+	// wave & 1: even waves read A_0 in phase A, odd waves A_1 in phase B
+	float csum = 0.f;
+	const bool do_colsum = a.cs_partials != nullptr;
+	const int cs_c = tid & 255;
+	const int cs_hc = (cs_c >> 7) * 64 + (cs_c & 63);  // column inside the half-tile
+	auto colsum_step = [&](uint32_t half_base) {
+#pragma unroll
+		for (int b4 = 0; b4 < 4; ++b4) {
+			uint32_t v[8];
+#pragma unroll
+			for (int e = 0; e < 8; ++e) {
+				const int kr = (tid >> 8) * 32 + 8 * b4 + e;
+				const uint32_t ad = half_base + kr * 256 + (((((cs_hc >> 4) ^ fk(kr)) << 1) | ((cs_hc >> 3) & 1)) << 4) + (cs_hc & 7) * 2;
+				asm volatile("ds_read_u16 %0, %1" : "=v"(v[e]) : "v"(ad));
+			}
+			asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7])::"memory");
+#pragma unroll
+			for (int e = 0; e < 8; ++e) csum += __builtin_bit_cast(float, v[e] << 16);
+		}
+	};
+
+	if (wr == 1) __builtin_amdgcn_s_barrier();  // the second wave row runs half a phase behind the first
+	int par = 0;
+	for (int kt = 0; kt < nt; ++kt) {
+		const uint32_t sb = lds0 + par * STEP_BYTES;
+		const bool cs_now = do_colsum && (k_begin / BK + kt) % a.tiles_n == tn;
+		s16x4 xa[4][2][2], xb[4][2][2];  // [fragment][k half][read]
+		// ---- phase A: B_0, B_1, A_0 -> row half 0; DMA: A_1 of the next K step ----
+		if (cs_now && (wave & 1) == 0) colsum_step(sb);
+#pragma unroll
+		for (int j = 0; j < 4; ++j)
+#pragma unroll
+			for (int s = 0; s < 2; ++s) {
+				lds_read_tr(xb[j][s][0], (sb + (2 + (j >> 1)) * HALF_BYTES + b_lane) ^ ((j & 1) << 5), 8192 * s);
+				lds_read_tr(xb[j][s][1], (sb + (2 + (j >> 1)) * HALF_BYTES + b_lane) ^ ((j & 1) << 5), 8192 * s + 1024);
+			}
+#pragma unroll
+		for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+			for (int s = 0; s < 2; ++s) {
+				lds_read_tr(xa[mi][s][0], (sb + a_lane) ^ (mi << 5), 8192 * s);
+				lds_read_tr(xa[mi][s][1], (sb + a_lane) ^ (mi << 5), 8192 * s + 1024);
+			}
+		asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+		stage_half(par ^ 1, 1, kt + 1);
+		asm volatile("s_waitcnt lgkmcnt(0)"
+					 : "+v"(xb[0][0][0]), "+v"(xb[0][0][1]), "+v"(xb[0][1][0]), "+v"(xb[0][1][1]), "+v"(xb[1][0][0]), "+v"(xb[1][0][1]), "+v"(xb[1][1][0]), "+v"(xb[1][1][1]),
+					   "+v"(xb[2][0][0]), "+v"(xb[2][0][1]), "+v"(xb[2][1][0]), "+v"(xb[2][1][1]), "+v"(xb[3][0][0]), "+v"(xb[3][0][1]), "+v"(xb[3][1][0]), "+v"(xb[3][1][1])
+					 :
+					 : "memory");
+		asm volatile(""
+					 : "+v"(xa[0][0][0]), "+v"(xa[0][0][1]), "+v"(xa[0][1][0]), "+v"(xa[0][1][1]), "+v"(xa[1][0][0]), "+v"(xa[1][0][1]), "+v"(xa[1][1][0]), "+v"(xa[1][1][1]),
+					   "+v"(xa[2][0][0]), "+v"(xa[2][0][1]), "+v"(xa[2][1][0]), "+v"(xa[2][1][1]), "+v"(xa[3][0][0]), "+v"(xa[3][0][1]), "+v"(xa[3][1][0]), "+v"(xa[3][1][1])
+					 :
+					 : "memory");
+		__builtin_amdgcn_s_barrier();
+		__builtin_amdgcn_sched_barrier(0);
+		__builtin_amdgcn_s_setprio(1);
+#pragma unroll
+		for (int s = 0; s < 2; ++s)
+#pragma unroll
+			for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+				for (int j = 0; j < 4; ++j)
+					acc[mi][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(join8(xb[j][s][0], xb[j][s][1]), join8(xa[mi][s][0], xa[mi][s][1]), acc[mi][j], 0, 0, 0);
+		__builtin_amdgcn_s_setprio(0);
+		__builtin_amdgcn_sched_barrier(0);
+		__builtin_amdgcn_s_barrier();
+		// ---- phase B: A_1 -> row half 1; DMA: A_0, B_0, B_1 of the K step after next ----
+		if (cs_now && (wave & 1) == 1) colsum_step(sb + HALF_BYTES);
+#pragma unroll
+		for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+			for (int s = 0; s < 2; ++s) {
+				lds_read_tr(xa[mi][s][0], (sb + HALF_BYTES + a_lane) ^ (mi << 5), 8192 * s);
+				lds_read_tr(xa[mi][s][1], (sb + HALF_BYTES + a_lane) ^ (mi << 5), 8192 * s + 1024);
+			}
+		asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+		stage_half(par, 0, kt + 2);
+		stage_half(par, 2, kt + 2);
+		stage_half(par, 3, kt + 2);
+		asm volatile("s_waitcnt lgkmcnt(0)"
+					 : "+v"(xa[0][0][0]), "+v"(xa[0][0][1]), "+v"(xa[0][1][0]), "+v"(xa[0][1][1]), "+v"(xa[1][0][0]), "+v"(xa[1][0][1]), "+v"(xa[1][1][0]), "+v"(xa[1][1][1]),
+					   "+v"(xa[2][0][0]), "+v"(xa[2][0][1]), "+v"(xa[2][1][0]), "+v"(xa[2][1][1]), "+v"(xa[3][0][0]), "+v"(xa[3][0][1]), "+v"(xa[3][1][0]), "+v"(xa[3][1][1])
+					 :
+					 : "memory");
+		__builtin_amdgcn_s_barrier();
+		__builtin_amdgcn_sched_barrier(0);
+		__builtin_amdgcn_s_setprio(1);
+#pragma unroll
+		for (int s = 0; s < 2; ++s)
+#pragma unroll
+			for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+				for (int j = 0; j < 4; ++j)
+					acc[4 + mi][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(join8(xb[j][s][0], xb[j][s][1]), join8(xa[mi][s][0], xa[mi][s][1]), acc[4 + mi][j], 0, 0, 0);
+		__builtin_amdgcn_s_setprio(0);
+		__builtin_amdgcn_sched_barrier(0);
+		__builtin_amdgcn_s_barrier();
+		par ^= 1;
+	}
+	if (wr == 0) __builtin_amdgcn_s_barrier();  // pairs with the second wave row's last barrier
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the trailing (unused) DMA must not outlive the workgroup's LDS
+	if (do_colsum) a.cs_partials[(((int64_t)split * a.tiles_n + tn) * 2 + (tid >> 8)) * g.M + m0 + cs_c] = csum;
+	// K-split partial tile straight from the accumulators in their own order; split_reduce_kernel adds the slices up
+	float* dst = a.partials + ((int64_t)split * ntile + (int64_t)tm * a.tiles_n + tn) * (BM * BN) + (int64_t)wave * (32 * 256) + lane * 4;
+#pragma unroll
+	for (int i = 0; i < 8; ++i)
+#pragma unroll
+		for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(dst + (i * 4 + j) * 256) = acc[i][j];
+}
+
 int p8_blocks() {
 	static int n = 0;
 	if (n == 0) {
@@ -329,4 +544,28 @@ int vitk_gemm_bf16_p8(const vitk_gemm_desc& d, hipStream_t st) {
 		case VITK_EPI_ACTGRAD: return d.act == VITK_ACT_GELU ? launch_p8<VITK_EPI_ACTGRAD, VITK_ACT_GELU>(a, st) : launch_p8<VITK_EPI_ACTGRAD, -1>(a, st);
 		default: return VITK_ERR_UNSUPPORTED;
 	}
+}
+
+bool vitk_gemm_bf16_p8w_ok(const WgradArgs& a) {
+	const GemmDev& g = a.g;
+	if (a.partials == nullptr || a.splits < 1) return false;
+	if (g.M % BM != 0 || g.N % BN != 0 || g.K % BK != 0 || a.k_per_split % BK != 0) return false;
+	if (g.lda % 8 != 0 || g.ldb % 8 != 0 || !vitk_aligned(g.A, 16) || !vitk_aligned(g.B, 16)) return false;
+	const int64_t last = g.K - (int64_t)(a.splits - 1) * a.k_per_split;  // the last K slice may be shorter
+	if (a.k_per_split < BK || last < BK) return false;  // (a one-step slice works: requests past the slice re-fetch its last step)
+	if ((int64_t)a.tiles_m * a.tiles_n * a.splits > (1ll << 30)) return false;
+	return true;
+}
+
+int vitk_gemm_bf16_p8w(const WgradArgs& a, hipStream_t st) {
+	if (!vitk_gemm_bf16_p8w_ok(a)) return VITK_ERR_UNSUPPORTED;
+	static bool attr = false;
+	if (!attr) {
+		hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_p8w_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+		if (e != hipSuccess) return VITK_ERR_HIP - (int)e;
+		attr = true;
+	}
+	hipLaunchKernelGGL(gemm_bf16_p8w_kernel, dim3((unsigned)(a.tiles_m * a.tiles_n * a.splits)), dim3(NTHREADS), LDS_BYTES, st, a);
+	VITK_CHECK_LAUNCH();
+	return VITK_OK;
 }

@@ -188,5 +188,15 @@ bool vitk_gemm_bf16_256_ok(const vitk_gemm_desc& d);  // large-tile LDS-DMA kern
 int vitk_gemm_bf16_256(const vitk_gemm_desc& d, hipStream_t st, bool* colsum_done);
 bool vitk_gemm_bf16_p8_ok(const vitk_gemm_desc& d);  // persistent 256x256 kernel with the deep operand pipeline (whole tiles, K-major x K-major, bf16 out)
 int vitk_gemm_bf16_p8(const vitk_gemm_desc& d, hipStream_t st);
+// Weight-gradient form of the same pipeline: both operands MN-major, float32 K-split partial tiles (accumulator order) into
+// `partials`, optional column sums of A (the bias gradient) into `cs_partials`; whole 256x256 tiles, K slices of >= 2 steps.
+struct WgradArgs {
+	GemmDev g;
+	int tiles_m, tiles_n, splits, k_per_split;
+	float* cs_partials;  // [split][tile column][row half][M] or null
+	float* partials;     // [split][tile][wave][i][j][lane][4]
+};
+bool vitk_gemm_bf16_p8w_ok(const WgradArgs& a);
+int vitk_gemm_bf16_p8w(const WgradArgs& a, hipStream_t st);
 bool vitk_gemm_bf16_t128_ok(const vitk_gemm_desc& d);  // 128x256-tile kernel, two workgroups per CU (K-major x K-major, bf16 out, K % 64 == 0)
 int vitk_gemm_bf16_t128(const vitk_gemm_desc& d, hipStream_t st);
