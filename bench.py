@@ -36,6 +36,9 @@ CVT = dict(chw=(3, 32, 32), out_d=10, batch=256, use_layer_scale=False, activati
 # BASELINE config 2: DeiT-style distillation of a ViT-Tiny student (with distillation token and head) from a frozen
 # CIFAR ResNet-20 teacher (deit_trainer.py:23-52, main.py:106-109 there), alpha 0.5, tau 1, batch 512
 DEIT = dict(CONFIGS["vit_tiny"], batch=512, alpha=0.5, tau=1.0)
+# BASELINE config 5: the conv + attention hybrid of the reference's older snapshot (_single_file.py:399-458, configuration
+# 562-570: dims 64/96/192/384/768, depths 2/2/3/5, 32 heads, SiLU, RMSNorm) at 224x224, 1000 classes, batch 128 per GPU
+COATNET = dict(dims=[64, 96, 192, 384, 768], depths=[2, 2, 3, 5, 2], num_heads=32, activation="silu", chw=(3, 224, 224), out_d=1000, batch=128)
 PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak of one MI355X
 
 
@@ -144,7 +147,7 @@ def main():
 	ap.add_argument("--warmup", type=int, default=3)
 	ap.add_argument("--graph", action="store_true", help="capture the training step into a HIP graph and replay it (single GPU)")
 	ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the config's)")
-	ap.add_argument("--config", default="vit_b16", choices=sorted(CONFIGS) + ["cvt", "deit_tiny"])
+	ap.add_argument("--config", default="vit_b16", choices=sorted(CONFIGS) + ["cvt", "deit_tiny", "coatnet"])
 	ap.add_argument("--dropout", type=float, default=0.0, help="config.dropout (attention-probability, branch and feed-forward dropouts)")
 	ap.add_argument("--no-cpu-baseline", action="store_true")
 	ap.add_argument("--no-kernel-timing", action="store_true")
@@ -172,12 +175,23 @@ def main():
 
 	is_cvt = args.config == "cvt"
 	is_deit = args.config == "deit_tiny"
-	c = CVT if is_cvt else (DEIT if is_deit else CONFIGS[args.config])
+	is_coat = args.config == "coatnet"
+	c = CVT if is_cvt else (DEIT if is_deit else (COATNET if is_coat else CONFIGS[args.config]))
 	batch = args.batch or c["batch"]
 	torch.manual_seed(0)
 	if is_cvt:
 		from vit_amd.models import CvT
 		model = CvT(make_cvt_config(args.dropout)).to(dev)
+	elif is_coat:
+		from vit_amd.layers import RMSNorm
+		from vit_amd.models import CoAtNet
+
+		class CoatCfg:
+			norm = RMSNorm
+			dropout = args.dropout
+		for k_ in ("dims", "depths", "num_heads", "activation", "chw", "out_d"):
+			setattr(CoatCfg, k_, c[k_])
+		model = CoAtNet(CoatCfg()).to(dev)
 	elif is_deit:
 		from vit_amd.models import DeiTViT
 		from vit_amd.models.teacher import frozen_teacher
@@ -255,6 +269,14 @@ def main():
 			"scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
 			"config": {"workload": "deit_tiny: ViT-Tiny/4 student with distillation token + head (d192/h3/L12/ff768, 66 tokens) distilled from a frozen CIFAR ResNet-20 "
 				f"teacher ({tsrc}; stock PyTorch-ROCm, no_grad), alpha {c['alpha']}, tau {c['tau']}, teacher fwd + student fwd + fused two-head loss + bwd + AdamW",
+				"global_batch": batch * world, "per_gpu_batch": batch, "parallelism": f"dp{world}", "hip_graph": bool(args.graph), "dropout": args.dropout},
+			"first_loss": None if first_loss is None else round(first_loss, 4), "final_loss": round(final_loss, 4), "lr": args.lr}), flush=True)
+	elif rank == 0 and is_coat:
+		print(json.dumps({"metric": "train images/sec (node) CoAtNet hybrid 224x224 bf16", "value": round(batch * world * args.steps / elapsed, 2), "unit": "images/sec",
+			"n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True,
+			"scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+			"config": {"workload": "coatnet: conv stem + MBConv stages (112^2 x 64, 56^2 x 96, 28^2 x 192) + 3 transformer blocks on 784 tokens x 384 (32 heads of 12) + "
+				"5 on 196 tokens x 768 (32 heads of 24), SiLU, RMSNorm, 1000 classes, fwd+CE+bwd+AdamW; throughput only (the reference's class cannot be constructed)",
 				"global_batch": batch * world, "per_gpu_batch": batch, "parallelism": f"dp{world}", "hip_graph": bool(args.graph), "dropout": args.dropout},
 			"first_loss": None if first_loss is None else round(first_loss, 4), "final_loss": round(final_loss, 4), "lr": args.lr}), flush=True)
 	elif rank == 0 and is_cvt:

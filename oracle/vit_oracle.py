@@ -500,6 +500,31 @@ def mbconv_fwd(x, sd, prefix, stride, activation, training=True):
 	return h
 
 
+def coatnet_fwd(x, sd, cfg, training=True):
+	"""The conv + attention hybrid of _single_file.py:399-458 (the constructible older text of models/coatnet.py) composed
+	from the pieces above, with the stem's convolution bias left out (it cancels in the BatchNorm behind it).  cfg: dims,
+	depths, num_heads, activation, norm.  PARITY UNPINNED as a whole (the reference's class cannot be constructed); MBConv
+	and the transformer block are pinned by their own goldens."""
+	act = cfg["activation"]
+	h = conv2d_fwd(x, sd["s0.conv.weight"], 2, 1)
+	h, _, _ = batchnorm2d_fwd(h, sd["s0.norm.weight"], sd["s0.norm.bias"], sd["s0.norm.running_mean"], sd["s0.norm.running_var"], training)
+	h = act_fwd(h, "gelu" if act.lower() == "gelu" else "silu")
+	for stage, depth in (("s1", cfg["depths"][0]), ("s2", cfg["depths"][1])):
+		for i in range(depth):
+			h = mbconv_fwd(h, sd, f"{stage}.{i}.", 2 if i == 0 else 1, act, training)
+	b, c, hh, ww = h.shape
+	t = h.reshape(b, c, hh * ww).transpose(1, 2)
+	t = linear_fwd(t, sd["s3_pe.weight"].reshape(sd["s3_pe.weight"].shape[0], -1), sd["s3_pe.bias"])
+	for i in range(cfg["depths"][2]):
+		t = vit_block_fwd(t, sd, f"s3.{i}.", cfg["num_heads"], cfg["norm"], act)
+	h = conv2d_fwd(tokens_to_nchw(t, hh, ww), sd["s4_pe.weight"], 2, 0) + sd["s4_pe.bias"].view(1, -1, 1, 1)
+	b, c, hh, ww = h.shape
+	t = h.reshape(b, c, hh * ww).transpose(1, 2)
+	for i in range(cfg["depths"][3]):
+		t = vit_block_fwd(t, sd, f"s4.{i}.", cfg["num_heads"], cfg["norm"], act)
+	return linear_fwd(t.mean(1), sd["head.weight"], sd["head.bias"])
+
+
 def tokens_to_nchw(x, h, w):
 	b, n, c = x.shape
 	return x.transpose(1, 2).reshape(b, c, h, w)

@@ -510,3 +510,57 @@ def test_deit_student_with_distillation_token(gpu, dtype):
 	model.eval()
 	with torch.no_grad():
 		assert relerr(model(x.to(gpu)), 0.5 * (wc + wd)) < tol
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("mode", ["train", "eval"])
+def test_coatnet_harness_against_the_oracle(gpu, dtype, mode):
+	"""The build-side conv + attention hybrid (stem, MBConv stages, 1x1 / 2x2 patch convolutions, transformer stages with
+	head sizes 12 and 24, pooled head), token-major end to end, against the oracle's composition of the same golden-pinned
+	blocks: logits, loss and every parameter gradient.  (No reference output exists for the whole model: its class cannot
+	be constructed.)"""
+	from oracle import vit_oracle as O
+	from vit_amd import ops
+	from vit_amd.layers import RMSNorm
+	from vit_amd.models import CoAtNet
+	cfg = dict(dims=[16, 24, 32, 48, 96], depths=[1, 2, 1, 2, 0], num_heads=4, activation="silu", norm="rmsnorm")
+
+	class Cfg:
+		dims, depths, num_heads, activation = cfg["dims"], cfg["depths"], cfg["num_heads"], cfg["activation"]
+		norm = RMSNorm
+		chw, out_d, dropout = (3, 32, 32), 10, 0.0
+	ops.clear_grad_sinks()
+	torch.manual_seed(5)
+	model = CoAtNet(Cfg()).to(gpu)
+	with torch.no_grad():  # norm weights away from their zero init, running statistics away from (0, 1)
+		for n, p in model.named_parameters():
+			if "norm" in n and n.endswith("weight") and p.dim() == 1 and "s0" not in n:
+				p.add_(0.1 * torch.randn_like(p))
+		for n, b in model.named_buffers():
+			if n.endswith("running_mean"):
+				b.add_(0.1 * torch.randn_like(b))
+			if n.endswith("running_var"):
+				b.mul_(1.0 + 0.2 * torch.rand_like(b))
+	model.train(mode == "train")
+	g = torch.Generator().manual_seed(6)
+	x = torch.randn(8, 3, 32, 32, generator=g)
+	y = torch.randint(0, 10, (8,), generator=g)
+	sd = {k: v.detach().float().cpu().clone() for k, v in model.state_dict().items()}
+	xg = x.to(gpu).requires_grad_(True)
+	with torch.autocast("cuda", dtype=torch.bfloat16, enabled=dtype == torch.bfloat16):
+		logits = model(xg)
+		loss = ops.cross_entropy(logits.float(), y.to(gpu))
+	loss.backward()
+	fwd = lambda im, s: O.coatnet_fwd(im, s, cfg, training=(mode == "train"))
+	wl, wloss, wg, wgx = O.loss_and_grads(fwd, sd, x, y)
+	tol, gtol = (TOL[dtype], GTOL[dtype]) if dtype == torch.float32 else (3e-2, 8e-2)  # bf16: three BatchNorm stages deep, as for CvT
+	assert relerr(logits, wl) < tol and relerr(loss, wloss) < tol
+	assert relerr(xg.grad, wgx) < gtol * (5 if dtype == torch.float32 else 1)
+	gmax = max(float(v.abs().max()) for v in wg.values())
+	for k, p in model.named_parameters():
+		assert p.grad is not None, k
+		if float(wg[k].abs().max()) < 1e-6 * gmax:
+			# an exactly-zero gradient (a BatchNorm bias whose shift the next training-mode BatchNorm removes): rounding noise only
+			assert float(p.grad.abs().max()) < 1e-3 * gmax, k
+			continue
+		assert relerr(p.grad, wg[k]) < gtol * (5 if dtype == torch.float32 else 1), k

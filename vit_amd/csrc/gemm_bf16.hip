@@ -445,7 +445,11 @@ int vitk_gemm_bf16(const vitk_gemm_desc& d, hipStream_t st, bool* colsum_done) {
 	// Problems whose 256x256 tiles leave the last round of the persistent kernel mostly empty (N = 768 at 50,432 rows: 591
 	// tiles = 2.3 rounds of 256) run on the 128x256-tile kernel, which balances the tail at half the granularity.
 	static const bool p8 = getenv("VITK_NO_P8") == nullptr;  // A-B switch
-	if (p8 && big_tiles && d.a_colsum == nullptr && vitk_gemm_bf16_p8_ok(d) && d.M * d.N >= 32ll * 256 * 256) return vitk_gemm_bf16_p8(d, st);
+	if (p8 && big_tiles && d.a_colsum == nullptr && vitk_gemm_bf16_p8_ok(d) && d.M * d.N >= 32ll * 256 * 256) {
+		// (Cutting a launch whose last round is mostly empty -- N = 768: 591 tiles = 2.31 rounds -- into whole rounds here plus
+		// the remaining rows on the 128x256-tile kernel was measured on the ViT-B/16 step: 0.6 ms slower, so it is not done.)
+		return vitk_gemm_bf16_p8(d, st);
+	}
 	static const bool t128 = getenv("VITK_NO_T128") == nullptr;  // A-B switch
 	if (t128 && big_tiles && vitk_gemm_bf16_t128_ok(d) && d.a_colsum == nullptr) {
 		const int64_t t256 = vitk_cdiv(d.M, 256) * vitk_cdiv(d.N, 256), t128n = vitk_cdiv(d.M, 128) * vitk_cdiv(d.N, 256);

@@ -24,14 +24,16 @@ class MBConv(nn.Module):
 			nn.Conv2d(hidden_dim, hidden_dim, 3, stride, 1, groups=hidden_dim, bias=False), nn.BatchNorm2d(hidden_dim), self.act_fn(),
 			nn.Conv2d(hidden_dim, out_chans, 1, 1, 0, bias=False), nn.BatchNorm2d(out_chans))
 
-	def forward(self, x):
+	def forward(self, x, hw=None):
+		"""x: NCHW as in the reference (NCHW out), or token-major [B, H*W, C] with hw = (H, W) (token-major out): what the
+		conv + attention hybrid passes from block to block, so that no layout conversion runs between them."""
 		c = self.conv
 		bns = (c[1], c[4], c[7])
 		assert all(b.eps == bns[0].eps and b.momentum == bns[0].momentum for b in bns)
 		if self.training:
 			for b in bns:
 				b.num_batches_tracked += 1
-		cfg = (self.stride, self.act_code, self.use_res_connect, bns[0].eps, bns[0].momentum, self.training)
+		cfg = (self.stride, self.act_code, self.use_res_connect, bns[0].eps, bns[0].momentum, self.training, hw)
 		return ops.MBConvFn.apply(x, c[0].weight, c[1].weight, c[1].bias, c[1].running_mean, c[1].running_var,
 			c[3].weight, c[4].weight, c[4].bias, c[4].running_mean, c[4].running_var,
 			c[6].weight, c[7].weight, c[7].bias, c[7].running_mean, c[7].running_var, cfg)

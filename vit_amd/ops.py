@@ -1211,17 +1211,25 @@ class MBConvFn(torch.autograd.Function):
 
 	@staticmethod
 	def forward(ctx, x, w1, g1, b1, rm1, rv1, wd, g2, b2, rm2, rv2, w3, g3, b3, rm3, rv3, cfg):
-		stride, act, use_res, eps, momentum, training = cfg
+		stride, act, use_res, eps, momentum, training = cfg[:6]
+		hw = cfg[6] if len(cfg) > 6 else None  # (H, W): x and the result are token-major [B, H*W, C] (no NCHW gathers at all)
 		L.require_gpu(x, w1)
 		lib = L.load()
 		dt = compute_dtype(x)
 		dtc = L.dtype_code(dt)
 		xc = cast(x, dt).contiguous()
-		Bn, Cin, H, W = xc.shape
 		hid, Cout = w1.shape[0], w3.shape[0]
-		R = Bn * H * W
-		t0 = torch.empty((R, Cin), dtype=dt, device=x.device)
-		L.check(lib.vitk_im2col(L.ptr(xc), L.ptr(t0), Bn, Cin, H, W, 1, 1, 0, 0, dtc, L.stream()))
+		if hw is None:
+			Bn, Cin, H, W = xc.shape
+			R = Bn * H * W
+			t0 = torch.empty((R, Cin), dtype=dt, device=x.device)
+			L.check(lib.vitk_im2col(L.ptr(xc), L.ptr(t0), Bn, Cin, H, W, 1, 1, 0, 0, dtc, L.stream()))
+		else:
+			Bn, S, Cin = xc.shape
+			H, W = hw
+			assert S == H * W
+			R = Bn * S
+			t0 = xc.reshape(R, Cin)
 
 		def bn(h, g, b, rm, rv):
 			y = torch.empty_like(h)
@@ -1246,8 +1254,11 @@ class MBConvFn(torch.autograd.Function):
 		if use_res:
 			n3 = scale_residual(n3, t0, None)
 		Ho, Wo = _conv_out(H, 3, stride, 1), _conv_out(W, 3, stride, 1)
-		y = torch.empty((Bn, Cout, Ho, Wo), dtype=dt, device=x.device)
-		L.check(lib.vitk_col2im(L.ptr(n3), L.ptr(y), Bn, Cout, Ho, Wo, 1, 1, 0, 0, dtc, L.stream()))
+		if hw is None:
+			y = torch.empty((Bn, Cout, Ho, Wo), dtype=dt, device=x.device)
+			L.check(lib.vitk_col2im(L.ptr(n3), L.ptr(y), Bn, Cout, Ho, Wo, 1, 1, 0, 0, dtc, L.stream()))
+		else:
+			y = n3.reshape(Bn, Ho * Wo, Cout)
 		ctx.save_for_backward(t0, h1, n1, a1, h2, n2, a2, h3, m1, r1, m2, r2, m3, r3, w1, wd, w3, g1, g2, g3)
 		ctx.meta = (x.shape, x.dtype, (b1, b2, b3), cfg, dt, (Bn, Cin, H, W, hid, Cout, Ho, Wo))
 		return y
@@ -1256,12 +1267,16 @@ class MBConvFn(torch.autograd.Function):
 	def backward(ctx, dy):
 		t0, h1, n1, a1, h2, n2, a2, h3, m1, r1, m2, r2, m3, r3, w1, wd, w3, g1, g2, g3 = ctx.saved_tensors
 		xshape, xdtype, (b1, b2, b3), cfg, dt, (Bn, Cin, H, W, hid, Cout, Ho, Wo) = ctx.meta
-		stride, act, use_res, eps, momentum, training = cfg
+		stride, act, use_res, eps, momentum, training = cfg[:6]
+		hw = cfg[6] if len(cfg) > 6 else None
 		lib = L.load()
 		dtc = L.dtype_code(dt)
 		dyc = cast(dy, dt).contiguous()
-		d3 = torch.empty((Bn * Ho * Wo, Cout), dtype=dt, device=dy.device)
-		L.check(lib.vitk_im2col(L.ptr(dyc), L.ptr(d3), Bn, Cout, Ho, Wo, 1, 1, 0, 0, dtc, L.stream()))
+		if hw is None:
+			d3 = torch.empty((Bn * Ho * Wo, Cout), dtype=dt, device=dy.device)
+			L.check(lib.vitk_im2col(L.ptr(dyc), L.ptr(d3), Bn, Cout, Ho, Wo, 1, 1, 0, 0, dtc, L.stream()))
+		else:
+			d3 = dyc.reshape(Bn * Ho * Wo, Cout)
 
 		def bn_bwd(dn, h, g, mean, rstd):
 			dh = torch.empty_like(h)
@@ -1289,12 +1304,85 @@ class MBConvFn(torch.autograd.Function):
 			dt0 = linear_dgrad(dh1, weight_as(w1, dt).reshape(hid, Cin))
 			if use_res:
 				dt0 = scale_residual(dt0, d3, None)
-			dx = torch.empty(xshape, dtype=dt, device=dy.device)
-			L.check(lib.vitk_col2im(L.ptr(dt0), L.ptr(dx), Bn, Cin, H, W, 1, 1, 0, 0, dtc, L.stream()))
+			if hw is None:
+				dx = torch.empty(xshape, dtype=dt, device=dy.device)
+				L.check(lib.vitk_col2im(L.ptr(dt0), L.ptr(dx), Bn, Cin, H, W, 1, 1, 0, 0, dtc, L.stream()))
+			else:
+				dx = dt0.reshape(xshape)
 			if dx.dtype != xdtype:
 				dx = cast(dx, xdtype)
 		return (dx, grad_as(dw1, w1), grad_as(dg1, g1), grad_as(db1, b1), None, None, grad_as(dwd, wd), grad_as(dg2, g2), grad_as(db2, b2), None, None,
 			grad_as(dw3, w3), grad_as(dg3, g3), grad_as(db3, b3), None, None, None)
+
+
+class ActFn(torch.autograd.Function):
+	"""y = act(x) as a stand-alone kernel (the activation behind a BatchNorm, where no GEMM epilogue can take it)."""
+
+	@staticmethod
+	def forward(ctx, x, act):
+		L.require_gpu(x)
+		xc = x.contiguous()
+		y = torch.empty_like(xc)
+		L.check(L.load().vitk_act_fwd(L.ptr(xc), L.ptr(y), xc.numel(), act, L.dtype_code(xc.dtype), L.stream()))
+		ctx.save_for_backward(xc)
+		ctx.act = act
+		return y
+
+	@staticmethod
+	def backward(ctx, dy):
+		(xc,) = ctx.saved_tensors
+		dyc = cast(dy, xc.dtype)
+		dx = torch.empty_like(xc)
+		L.check(L.load().vitk_act_bwd(L.ptr(dyc), L.ptr(xc), L.ptr(dx), xc.numel(), ctx.act, L.dtype_code(xc.dtype), L.stream()))
+		return dx, None
+
+
+class ConvTokensFn(torch.autograd.Function):
+	"""Conv2d with bias and no normalisation behind it, tokens out: im2col gather + MFMA GEMM with the bias in its epilogue.
+	Input NCHW, or token-major [B, H*W, C] with hw = (H, W).  (The patch-merging convolutions between the stages of a
+	conv + attention hybrid; a 1x1 convolution on tokens is a plain Linear and needs no gather.)"""
+
+	@staticmethod
+	def forward(ctx, x, w, b, cfg):
+		ks, stride, pad, hw = cfg
+		L.require_gpu(x, w)
+		lib = L.load()
+		dt = compute_dtype(x)
+		xc = cast(x, dt)
+		if hw is None:
+			Bn, C, H, W = xc.shape
+			tokens_in = 0
+		else:
+			Bn, S, C = xc.shape
+			H, W = hw
+			assert S == H * W
+			tokens_in = 1
+		Ho, Wo = _conv_out(H, ks, stride, pad), _conv_out(W, ks, stride, pad)
+		Cout, K = w.shape[0], C * ks * ks
+		assert K % 8 == 0 or dt == torch.float32, "bf16: C * k * k must be a multiple of 8"
+		dtc = L.dtype_code(dt)
+		cols = torch.empty((Bn * Ho * Wo, K), dtype=dt, device=x.device)
+		L.check(lib.vitk_im2col(L.ptr(xc), L.ptr(cols), Bn, C, H, W, ks, stride, pad, tokens_in, dtc, L.stream()))
+		y = linear_fwd(cols, weight_as(w, dt).reshape(Cout, K), f32(b))
+		ctx.save_for_backward(cols, w)
+		ctx.meta = (x.shape, x.dtype, b, cfg, dt, (Bn, C, H, W, tokens_in))
+		return y.reshape(Bn, Ho * Wo, Cout)
+
+	@staticmethod
+	def backward(ctx, dy):
+		cols, w = ctx.saved_tensors
+		xshape, xdtype, b, (ks, stride, pad, hw), dt, (Bn, C, H, W, tokens_in) = ctx.meta
+		Cout = w.shape[0]
+		dy2 = _flat(cast(dy, dt))
+		dw, db = linear_wgrad(dy2, cols, bias_grad=b is not None)
+		dx = None
+		if ctx.needs_input_grad[0]:
+			dcols = linear_dgrad(dy2, weight_as(w, dt).reshape(Cout, -1))
+			dx = torch.empty(xshape, dtype=dt, device=dy.device)
+			L.check(L.load().vitk_col2im(L.ptr(dcols), L.ptr(dx), Bn, C, H, W, ks, stride, pad, tokens_in, L.dtype_code(dt), L.stream()))
+			if dx.dtype != xdtype:
+				dx = cast(dx, xdtype)
+		return dx, grad_as(dw.reshape(w.shape), w), grad_as(db, b), None
 
 
 class MeanPoolFn(torch.autograd.Function):
