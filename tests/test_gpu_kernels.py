@@ -335,7 +335,10 @@ def test_norms(gpu, dtype, kind, rows, d):
 
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("B,h,Sq,Skv,dh", [(2, 3, 65, 65, 64), (2, 12, 197, 197, 64), (3, 4, 17, 17, 12), (2, 2, 50, 13, 24), (2, 6, 4, 1, 64), (1, 1, 300, 300, 64), (2, 2, 16, 4, 32),
-	(70, 12, 65, 65, 64), (67, 9, 40, 24, 64)])  # the last two: more (batch, head) pairs than CUs (several pairs per workgroup, ragged last workgroup)
+	(70, 12, 65, 65, 64), (67, 9, 40, 24, 64),  # these two: more (batch, head) pairs than CUs (several pairs per workgroup, ragged last workgroup)
+	# key-blocked online-softmax kernels (bf16): the conv + attention hybrid's stages, a CvT-sized first stage, ragged blocks, every head-size class
+	(2, 4, 784, 784, 12), (2, 4, 196, 196, 24), (1, 2, 3136, 3136, 64), (1, 2, 300, 77, 40), (1, 3, 129, 64, 8), (1, 1, 64, 64, 4), (2, 2, 257, 513, 48), (1, 2, 5, 1, 20),
+	(1, 2, 1, 130, 16), (1, 2, 260, 260, 64)])
 def test_attention(gpu, dtype, B, h, Sq, Skv, dh):
 	from vit_amd import ops
 	d = h * dh
@@ -401,10 +404,11 @@ def test_attention_dropout(gpu, dtype, B, h, Sq, Skv, dh, p):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-def test_attention_strided_qkv(gpu, dtype):
+@pytest.mark.parametrize("S,dh", [(33, 64), (90, 12), (300, 64)])
+def test_attention_strided_qkv(gpu, dtype, S, dh):
 	"""q/k/v as column slices of one fused [rows, 3d] buffer (the layout MHA uses)."""
 	from vit_amd import ops
-	B, h, S, dh = 2, 2, 33, 64
+	B, h = 2, 2
 	d = h * dh
 	qkv, qkvr = rnd((B * S, 3 * d), dtype, gpu, seed=1)
 	out, lse = ops.attention_fwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], B, h, S, S, dh)

@@ -43,3 +43,6 @@ int vitk_attention_generic(const AttnArgs& a, bool bwd, int dtype, hipStream_t s
 // bf16 MFMA kernels; return VITK_ERR_UNSUPPORTED when the shape does not qualify
 bool vitk_attention_mfma_ok(const AttnArgs& a, int dtype);
 int vitk_attention_mfma(const AttnArgs& a, bool bwd, hipStream_t st);
+// bf16 MFMA kernels for any sequence length and head sizes 4, 8, ..., 64 (keys walked in blocks of 64, online softmax); no dropout
+bool vitk_attention_flash_ok(const AttnArgs& a, int dtype);
+int vitk_attention_flash(const AttnArgs& a, bool bwd, hipStream_t st);

@@ -1,5 +1,5 @@
-// C ABI of the attention core: argument validation and dispatch between the bf16 MFMA kernels and
-// the generic vector-ALU kernels.
+// C ABI of the attention core: argument validation and dispatch between the bf16 MFMA kernels (whole key set in LDS for
+// head size 64 and at most 256 tokens; blocked online softmax for the rest) and the generic vector-ALU kernels.
 #include "attention.h"
 
 #include <mutex>
@@ -41,6 +41,7 @@ extern "C" int vitk_attention_fwd_dropout(const void* q, const void* k, const vo
 	rc = set_dropout(a, dropout_p, seed);
 	if (rc != VITK_OK) return rc;
 	if (vitk_attention_mfma_ok(a, dtype)) return vitk_attention_mfma(a, false, (hipStream_t)stream);
+	if (vitk_attention_flash_ok(a, dtype)) return vitk_attention_flash(a, false, (hipStream_t)stream);
 	return vitk_attention_generic(a, false, dtype, (hipStream_t)stream);
 }
 
@@ -68,6 +69,7 @@ extern "C" int vitk_attention_bwd_dropout(const void* dout, const void* q, const
 	rc = set_dropout(a, dropout_p, seed);
 	if (rc != VITK_OK) return rc;
 	if (vitk_attention_mfma_ok(a, dtype)) return vitk_attention_mfma(a, true, (hipStream_t)stream);
+	if (vitk_attention_flash_ok(a, dtype)) return vitk_attention_flash(a, true, (hipStream_t)stream);
 	return vitk_attention_generic(a, true, dtype, (hipStream_t)stream);
 }
 

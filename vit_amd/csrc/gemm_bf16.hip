@@ -434,7 +434,7 @@ bool vitk_gemm_bf16_ok(const vitk_gemm_desc& d) {
 	if (d.ldb % 8 != 0) return false;
 	if (d.b_layout == VITK_MN_MAJOR && d.N % 8 != 0) return false;
 	// tiny problems: the generic kernel's 64x64 tiles waste less
-	if (d.M * d.N < 64 * 64 || d.K < 32) return false;
+	if ((d.M * d.N < 64 * 64 && d.K < 4096) || d.K < 32) return false;  // (a tiny output over a very long K -- the weight gradient of a narrow convolution -- still wants the K-split MFMA kernel)
 	if (vitk_cdiv(d.M, BM) * vitk_cdiv(d.N, BN) > (1ll << 30)) return false;
 	return true;
 }
