@@ -79,6 +79,31 @@ __device__ __forceinline__ void stage_rows(char* img, const bf16_t* src, int64_t
 	}
 }
 
+// The same staging split in two so that a block's global loads fly while the previous block is computed on: the loads
+// into registers (NIT = ceil(64 * dh4 / 256) 8-byte pieces per thread), and later the stores into the image.
+template <int NIT>
+__device__ __forceinline__ void fetch_rows(uint2 (&r)[NIT], const bf16_t* src, int64_t ld, int row0, int total, int dh4) {
+#pragma unroll
+	for (int i = 0; i < NIT; ++i) {
+		const int idx = threadIdx.x + 256 * i;
+		if (idx < 64 * dh4) {
+			const int row = idx / dh4, c4 = idx - row * dh4;
+			r[i] = *reinterpret_cast<const uint2*>(src + (int64_t)min(row0 + row, total - 1) * ld + 4 * c4);
+		}
+	}
+}
+template <int NIT>
+__device__ __forceinline__ void commit_rows(char* img, const uint2 (&r)[NIT], int dh4) {
+#pragma unroll
+	for (int i = 0; i < NIT; ++i) {
+		const int idx = threadIdx.x + 256 * i;
+		if (idx < 64 * dh4) {
+			const int row = idx / dh4, c4 = idx - row * dh4;
+			*reinterpret_cast<uint2*>(img + img_off(row, c4 >> 1) + ((c4 & 1) << 3)) = r[i];
+		}
+	}
+}
+
 // 4 consecutive head columns d0 .. d0 + 3 of one row, if they belong to the head
 __device__ __forceinline__ void store4(bf16_t* row, int d0, int dh, const f32x4& v, float mul) {
 	if (d0 < dh) {
@@ -113,11 +138,18 @@ __global__ __launch_bounds__(256) void attn_flash_fwd_kernel(AttnArgs a) {
 	f32x4 o[NDT];
 #pragma unroll
 	for (int dt = 0; dt < NDT; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+	uint2 kr[NDT], vr[NDT];
+	fetch_rows(kr, kb, a.ldk, 0, a.Skv, dh4);
+	fetch_rows(vr, vb, a.ldv, 0, a.Skv, dh4);
 	for (int k0 = 0; k0 < a.Skv; k0 += 64) {
 		__syncthreads();  // every wave is done with the previous block's images
-		stage_rows(Ks, kb, a.ldk, k0, a.Skv, dh4);
-		stage_rows(Vs, vb, a.ldv, k0, a.Skv, dh4);
+		commit_rows(Ks, kr, dh4);
+		commit_rows(Vs, vr, dh4);
 		__syncthreads();
+		if (k0 + 64 < a.Skv) {  // the next block's rows are on their way while this one is worked on
+			fetch_rows(kr, kb, a.ldk, k0 + 64, a.Skv, dh4);
+			fetch_rows(vr, vb, a.ldv, k0 + 64, a.Skv, dh4);
+		}
 		f32x4 st[4];
 		float bm = -INFINITY;
 #pragma unroll
@@ -207,11 +239,18 @@ __global__ __launch_bounds__(256) void attn_flash_dq_kernel(AttnArgs a) {
 	f32x4 dq[NDT];
 #pragma unroll
 	for (int dt = 0; dt < NDT; ++dt) dq[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+	uint2 kr[NDT], vr[NDT];
+	fetch_rows(kr, kb, a.ldk, 0, a.Skv, dh4);
+	fetch_rows(vr, vb, a.ldv, 0, a.Skv, dh4);
 	for (int k0 = 0; k0 < a.Skv; k0 += 64) {
 		__syncthreads();  // (first pass: every wave has taken its O fragments out of the image that now receives K)
-		stage_rows(Ks, kb, a.ldk, k0, a.Skv, dh4);
-		stage_rows(Vs, vb, a.ldv, k0, a.Skv, dh4);
+		commit_rows(Ks, kr, dh4);
+		commit_rows(Vs, vr, dh4);
 		__syncthreads();
+		if (k0 + 64 < a.Skv) {
+			fetch_rows(kr, kb, a.ldk, k0 + 64, a.Skv, dh4);
+			fetch_rows(vr, vb, a.ldv, k0 + 64, a.Skv, dh4);
+		}
 #pragma unroll
 		for (int u = 0; u < 2; ++u) {
 			f32x4 ds[2];
@@ -271,17 +310,30 @@ __global__ __launch_bounds__(256) void attn_flash_dkv_kernel(AttnArgs a) {
 	f32x4 dk[NDT], dv[NDT];
 #pragma unroll
 	for (int dt = 0; dt < NDT; ++dt) dk[dt] = dv[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+	uint2 qr[NDT], gr[NDT];
+	float stat = 0.f;  // threads 0..63: lse of query q0 + t; 64..127: delta of query q0 + t - 64
+	auto fetch_stat = [&](int q0) {
+		if (threadIdx.x < 128) {
+			const int q = q0 + (threadIdx.x & 63);
+			const bool is_lse = threadIdx.x < 64;
+			// probabilities of padded queries: exp2(s - inf) = 0
+			stat = q < a.Sq ? a.bwd_scratch[((int64_t)(is_lse ? 0 : n_bh) + bh) * a.Sq + q] : (is_lse ? INFINITY : 0.f);
+		}
+	};
+	fetch_rows(qr, qb, a.ldq, 0, a.Sq, dh4);
+	fetch_rows(gr, gb, a.ldo, 0, a.Sq, dh4);
+	fetch_stat(0);
 	for (int q0 = 0; q0 < a.Sq; q0 += 64) {
 		__syncthreads();
-		stage_rows(Qs, qb, a.ldq, q0, a.Sq, dh4);
-		stage_rows(Gs, gb, a.ldo, q0, a.Sq, dh4);
-		if (threadIdx.x < 64) {
-			const int q = q0 + threadIdx.x;
-			const bool in = q < a.Sq;
-			lse_s[threadIdx.x] = in ? a.bwd_scratch[(int64_t)bh * a.Sq + q] : INFINITY;  // probabilities of padded queries: exp2(-inf) = 0
-			delta_s[threadIdx.x] = in ? a.bwd_scratch[((int64_t)n_bh + bh) * a.Sq + q] : 0.f;
-		}
+		commit_rows(Qs, qr, dh4);
+		commit_rows(Gs, gr, dh4);
+		if (threadIdx.x < 128) lse_s[threadIdx.x] = stat;  // delta_s follows lse_s
 		__syncthreads();
+		if (q0 + 64 < a.Sq) {
+			fetch_rows(qr, qb, a.ldq, q0 + 64, a.Sq, dh4);
+			fetch_rows(gr, gb, a.ldo, q0 + 64, a.Sq, dh4);
+			fetch_stat(q0 + 64);
+		}
 #pragma unroll
 		for (int u = 0; u < 2; ++u) {
 			f32x4 pr[2], ds[2];
