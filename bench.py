@@ -316,11 +316,11 @@ def main():
 			# HBM-side bytes per launch of that kernel: PMC counters cannot be read from inside this process; they come from
 			# separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same command (tools/pmc_traffic.py)
 			traffic, traffic_src = None, None
-			tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1_pmc_hbm_traffic.json")
+			tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r2_pmc_hbm_traffic.json")
 			if args.config == "vit_b16" and os.path.exists(tpath):
 				rec = json.load(open(tpath)).get(label)
 				if rec:
-					traffic, traffic_src = round(rec["traffic_bytes_per_step"] * args.steps / n), "profiles/r1_pmc_hbm_traffic.json"
+					traffic, traffic_src = round(rec["traffic_bytes_per_step"] * args.steps / n), "profiles/r2_pmc_hbm_traffic.json"
 			out["roofline"] = {"bound": "mfma", "kernel": label, "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
 				"frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "launches": n, "avg_launch_ms": round(1e3 * sec / n, 4),
 				"gflop_per_launch": round(fl / n / 1e9, 2),
@@ -328,12 +328,12 @@ def main():
 				"all_gemm_kernels": {k: {"tflops": round(v[0] / v[1] / 1e12, 1), "ms_per_step": round(1e3 * v[1] / args.steps, 3), "launches_per_step": v[2] // args.steps} for k, v in agg.items()}}
 			# matrix-pipe busy fraction of the same workload from an SQ counter pass (SQ_VALU_MFMA_BUSY_CYCLES over
 			# 4 x SQ_BUSY_CU_CYCLES, i.e. against the clock the chip actually ran at): recorded, not measured in this run
-			spath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1_pmc_sq_counters.json")
+			spath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r2_pmc_sq_counters.json")
 			if args.config == "vit_b16" and os.path.exists(spath):
 				for key, rec in json.load(open(spath)).items():
 					if key.startswith("whole training step"):
 						out["roofline"]["mfma_pipe_busy_frac_whole_step_pmc"] = round(rec["derived_mfma_pipe_busy_frac"], 4)
-						out["roofline"]["mfma_pipe_busy_source"] = "profiles/r1_pmc_sq_counters.json"
+						out["roofline"]["mfma_pipe_busy_source"] = "profiles/r2_pmc_sq_counters.json"
 		if not args.no_cpu_baseline and world == 1:
 			out["cpu_baseline"] = cpu_baseline(c)
 		print(json.dumps(out), flush=True)

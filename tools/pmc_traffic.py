@@ -17,10 +17,10 @@ import sys
 
 
 def label_of(kernel_name):
-	"""bench.py's GEMM label (operand layouts) of a kernel instantiation, or None."""
-	m = re.search(r"gemm_bf16(?:_256p?)?_kernel<(\d), (\d)", kernel_name) or re.search(r"gemm_bf16(?:_256p?)?_kernelILi(\d)ELi(\d)E", kernel_name)
+	"""bench.py's GEMM label (the kernel family vitk_gemm_last_kernel() reports) of a kernel instantiation, or None."""
+	m = re.search(r"gemm_(bf16_p8w|bf16_p8|bf16_t128|bf16_256p?|bf16|generic)_kernel", kernel_name)
 	if m:
-		return f"gemm_bf16_mfma<A{m.group(1)},B{m.group(2)}>"
+		return "gemm_" + m.group(1).replace("256p", "256") + "_kernel"
 	return None
 
 

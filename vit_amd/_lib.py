@@ -48,6 +48,7 @@ SIGNATURES = {
 	"vitk_version": [],
 	"vitk_gemm": [POINTER(GemmDesc), P],
 	"vitk_gemm_uses_bf16_mfma": [POINTER(GemmDesc)],
+	"vitk_gemm_last_kernel": [],
 	"vitk_gemm_workspace_bytes": [],
 	"vitk_layernorm_fwd": [P, P, P, P, P, P, P, P, I64, I64, FL, I, P],
 	"vitk_layernorm_bwd": [P, P, P, P, P, P, P, P, P, I64, I64, I, P],
@@ -91,7 +92,7 @@ SIGNATURES = {
 	"vitk_batchnorm_fwd": [P, P, P, P, P, P, P, P, I64, I64, FL, FL, I, I, P],
 	"vitk_batchnorm_bwd": [P, P, P, P, P, P, P, P, I64, I64, I, I, P],
 }
-_RESTYPES = {"vitk_strerror": c_char_p, "vitk_gemm_workspace_bytes": c_int64}
+_RESTYPES = {"vitk_strerror": c_char_p, "vitk_gemm_workspace_bytes": c_int64, "vitk_gemm_last_kernel": c_char_p}
 
 _lib = None
 

@@ -464,6 +464,7 @@ int vitk_gemm_bf16(const vitk_gemm_desc& d, hipStream_t st, bool* colsum_done) {
 }
 
 int vitk_gemm_bf16_128(const vitk_gemm_desc& d, hipStream_t st, bool* colsum_done) {
+	vitk_last_gemm_kernel = "gemm_bf16_kernel";
 	BfArgs a{};
 	a.g = make_gemm_dev(d);
 	a.tiles_m = (int)vitk_cdiv(d.M, BM);

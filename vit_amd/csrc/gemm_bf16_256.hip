@@ -962,8 +962,12 @@ int vitk_gemm_bf16_256(const vitk_gemm_desc& d, hipStream_t st, bool* colsum_don
 	{
 		bool handled = false;
 		const int rc = split_off_partial_round(d, st, &handled);
-		if (handled) return rc;
+		if (handled) {
+			vitk_last_gemm_kernel = "gemm_bf16_256_kernel";  // (the bulk of the split launch)
+			return rc;
+		}
 	}
+	vitk_last_gemm_kernel = "gemm_bf16_256_kernel";
 	BigArgs a{};
 	a.g = make_gemm_dev(d);
 	a.a_colsum = d.a_colsum;

@@ -528,6 +528,7 @@ bool vitk_gemm_bf16_p8_ok(const vitk_gemm_desc& d) {
 }
 
 int vitk_gemm_bf16_p8(const vitk_gemm_desc& d, hipStream_t st) {
+	vitk_last_gemm_kernel = "gemm_bf16_p8_kernel";
 	P8Args a{};
 	a.g = make_gemm_dev(d);
 	a.tiles_m = (int)vitk_cdiv(d.M, BM);
@@ -559,6 +560,7 @@ bool vitk_gemm_bf16_p8w_ok(const WgradArgs& a) {
 
 int vitk_gemm_bf16_p8w(const WgradArgs& a, hipStream_t st) {
 	if (!vitk_gemm_bf16_p8w_ok(a)) return VITK_ERR_UNSUPPORTED;
+	vitk_last_gemm_kernel = "gemm_bf16_p8w_kernel";
 	static bool attr = false;
 	if (!attr) {
 		hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_p8w_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);

@@ -289,6 +289,7 @@ bool vitk_gemm_bf16_t128_ok(const vitk_gemm_desc& d) {
 }
 
 int vitk_gemm_bf16_t128(const vitk_gemm_desc& d, hipStream_t st) {
+	vitk_last_gemm_kernel = "gemm_bf16_t128_kernel";
 	T128Args a{};
 	a.g = make_gemm_dev(d);
 	a.tiles_m = (int)vitk_cdiv(d.M, TM);

@@ -179,6 +179,7 @@ __device__ __forceinline__ void epi_store4(const GemmDev& g, int64_t m, int64_t 
 	store_vec<TOUT, 4>(c, v);
 }
 
+extern thread_local const char* vitk_last_gemm_kernel;  // set by every GEMM launcher
 int vitk_gemm_generic(const vitk_gemm_desc& d, hipStream_t st);
 // *colsum_done is set when the kernel that ran also accumulated d.a_colsum
 int vitk_gemm_bf16(const vitk_gemm_desc& d, hipStream_t st, bool* colsum_done);

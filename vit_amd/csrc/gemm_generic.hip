@@ -72,7 +72,10 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(GemmDev g) {
 
 }  // namespace
 
+thread_local const char* vitk_last_gemm_kernel = "";
+
 int vitk_gemm_generic(const vitk_gemm_desc& d, hipStream_t st) {
+	vitk_last_gemm_kernel = "gemm_generic_kernel";
 	GemmDev g = make_gemm_dev(d);
 	dim3 grid((unsigned)vitk_cdiv(d.N, BN), (unsigned)vitk_cdiv(d.M, BM));
 	VITK_REQUIRE(vitk_cdiv(d.M, BM) <= 65535, VITK_ERR_SHAPE);
@@ -132,6 +135,8 @@ extern "C" int vitk_gemm(const vitk_gemm_desc* desc, void* stream) {
 	// the kernel that ran does not fuse the column sums of A: A is [K rows][M columns] here
 	return vitk_colsum(d.A, d.a_colsum, d.K, d.M, d.lda, 1, d.in_dtype, stream);
 }
+
+extern "C" const char* vitk_gemm_last_kernel(void) { return vitk_last_gemm_kernel; }
 
 extern "C" int vitk_gemm_uses_bf16_mfma(const vitk_gemm_desc* desc) {
 	if (desc == nullptr) return 0;
