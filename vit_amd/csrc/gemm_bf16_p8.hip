@@ -131,7 +131,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_p8_kernel(P8Args a) {
 				const char* src = reinterpret_cast<const char*>(A + row0 * g.lda + k0) + a_voff;
 				__builtin_amdgcn_global_load_lds((gbl_void_p)src, (lds_void_p)(dst + p * 1024), 16, 0, 0);
 			} else {
-				const int64_t col0 = tn0 + (p >> 2) * 64 + (which - 2) * 32 + 8 * (p & 3);
+				// (N is a multiple of 64, not necessarily of 256: a piece past the last column re-fetches the last 8 columns, and the
+				// waves that own those columns skip their epilogue)
+				const int64_t col0 = min(tn0 + (p >> 2) * 64 + (which - 2) * 32 + 8 * (p & 3), g.N - 8);
 				const char* src = reinterpret_cast<const char*>(B + col0 * g.ldb + k0) + b_voff;
 				__builtin_amdgcn_global_load_lds((gbl_void_p)src, (lds_void_p)(dst + p * 1024), 16, 0, 0);
 			}
@@ -168,6 +170,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_p8_kernel(P8Args a) {
 	__builtin_amdgcn_s_barrier();
 
 	int par = 0;  // LDS buffer of the current K step
+	bool epi_pending = false;  // this wave's previous epilogue left its N_EPI memory operations in flight (wave-uniform)
 	for (int round = 0; have; ++round) {
 		P8STAMP(0);
 		f32x4 acc[8][4];
@@ -194,7 +197,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_p8_kernel(P8Args a) {
 				for (int s = 0; s < 2; ++s) lds_read128(xa[mi][s], (sb + a_lane) ^ (s << 6), 2048 * mi);
 			// all but the six newest requests (A_0, B_0, B_1 of the next K step) have landed: this step's A_1 is in LDS.  In
 			// the first K step of a tile the previous epilogue's loads and stores are newer still and stay in flight too.
-			if (kt == 0 && round > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 + N_EPI) : "memory");
+			if (kt == 0 && epi_pending) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 + N_EPI) : "memory");
 			else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
 			stage_ahead(par ^ 1, 1, kt, 1);
 			asm volatile("s_waitcnt lgkmcnt(0)"
@@ -222,7 +225,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_p8_kernel(P8Args a) {
 #pragma unroll
 				for (int s = 0; s < 2; ++s) lds_read128(xa[mi][s], (sb + HALF_BYTES + a_lane) ^ (s << 6), 2048 * mi);
 			// all but the two newest requests (A_1 of the next K step) have landed: the next K step's A_0, B_0, B_1 are in LDS
-			if (kt == 0 && round > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 + N_EPI) : "memory");
+			if (kt == 0 && epi_pending) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 + N_EPI) : "memory");
 			else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
 			stage_ahead(par, 0, kt, 2);
 			stage_ahead(par, 2, kt, 2);
@@ -253,9 +256,18 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_p8_kernel(P8Args a) {
 		asm volatile("" ::: "memory");
 		__builtin_amdgcn_sched_barrier(0);
 		const int64_t m0w = m0 + wr * 128, n0w = n0 + wc * 64;
-		EpiRegs er;  // (the host only launches this kernel on whole tiles with 16-byte accessible operands)
-		epilogue_prefetch<EPI>(g, er, true, n0w, lane);
-		epilogue_wave<EPI, ACT, false>(g, acc, er, true, img, m0w, n0w, lane);
+		// (the host only launches this kernel on whole row tiles and 64-column wave slices with 16-byte accessible operands; a
+		// wave whose slice lies past the last column has nothing to store)
+		epi_pending = n0w < g.N;
+		if (epi_pending) {
+			// (an opaque copy of the lane index: lane-dependent epilogue addresses formed from the original are hoisted above
+			// the main loop, spilled there, and their reload here waits for every operand request in flight)
+			int lane_e = lane;
+			asm volatile("" : "+v"(lane_e));
+			EpiRegs er;
+			epilogue_prefetch<EPI>(g, er, true, n0w, lane_e);
+			epilogue_wave<EPI, ACT, false>(g, acc, er, true, img, m0w, n0w, lane_e);
+		}
 		P8STAMP(2);
 #ifdef VITK_P8_STAMPS
 		if (a.stamps != nullptr && round == 0 && lane == 0 && blockIdx.x == 8)
@@ -520,7 +532,8 @@ bool vitk_gemm_bf16_p8_ok(const vitk_gemm_desc& d) {
 	if (d.patch_grid > 0 || d.tokens_per_image > 0 || d.K % BK != 0 || d.K < 2 * BK) return false;
 	if (d.a_layout != VITK_K_MAJOR || d.b_layout != VITK_K_MAJOR) return false;
 	if (d.in_dtype != VITK_BF16 || d.out_dtype != VITK_BF16 || d.accumulate) return false;
-	if (d.M % BM != 0 || d.N % BN != 0) return false;  // whole tiles only: the kernel has no edge handling
+	// whole row tiles; columns in whole 64-wide wave slices, at least half of the last tile column in use
+	if (d.M % BM != 0 || d.N % 64 != 0 || 2 * d.N < vitk_cdiv(d.N, BN) * BN) return false;
 	auto al16 = [](const void* p) { return p == nullptr || vitk_aligned(p, 16); };
 	if (d.ldc % 8 != 0 || d.ld_aux % 8 != 0 || d.ld_out2 % 8 != 0 || !al16(d.C) || !al16(d.bias) || !al16(d.gamma) || !al16(d.aux) || !al16(d.out2)) return false;
 	if (d.lda % 8 != 0 || d.ldb % 8 != 0 || !al16(d.A) || !al16(d.B)) return false;
