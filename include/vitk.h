@@ -156,6 +156,13 @@ int vitk_rmsnorm_fwd(const void* x, const void* res, const float* weight, void* 
 	int64_t rows, int64_t d, float eps, int unit_offset, int dtype, void* stream);
 int vitk_rmsnorm_bwd(const void* dy, const void* x, const float* weight, const float* rstd, const void* dres,
 	void* dx, float* dweight, int64_t rows, int64_t d, int unit_offset, int dtype, void* stream);
+/* DyT, the dynamic-tanh stand-in for a norm (layers/norm.py:35-45): y = gamma * tanh(alpha[0] * x) + beta over the last
+ * dimension d (<= 4096 with 16-byte accessible rows and d % 4 == 0, else <= 1024).  Backward: dx, and dalpha (1 float),
+ * dgamma, dbeta ([d] floats) ACCUMULATED into (the caller zeroes them). */
+int vitk_dyt_fwd(const void* x, const float* alpha, const float* gamma, const float* beta, void* y, int64_t rows, int64_t d,
+	int dtype, void* stream);
+int vitk_dyt_bwd(const void* dy, const void* x, const float* alpha, const float* gamma, void* dx, float* dalpha, float* dgamma,
+	float* dbeta, int64_t rows, int64_t d, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Multi-head attention core: F.scaled_dot_product_attention(q,k,v,is_causal=False)
@@ -209,6 +216,10 @@ int vitk_attention_bwd_noalloc(const void* dout, const void* q, const void* k, c
  */
 /* dst[i] = (dst_dtype) src[i] */
 int vitk_cast(const void* src, void* dst, int64_t n, int src_dtype, int dst_dtype, void* stream);
+/* y[i] = x[i] * g[0] with g one float in device memory: the upstream gradient of a scalar loss applied to the stored
+ * d(loss)/d(logits) (autograd's backward of nn.CrossEntropyLoss / the DeiT loss, main.py:106-109, deit_trainer.py:30-45)
+ * without reading g back to the host. */
+int vitk_scale_by(const void* x, const float* g, void* y, int64_t n, int dtype, void* stream);
 /* y[c*ldy + r] = x[r*ldx + c] for r < rows, c < cols.  No counterpart op in the reference: it keeps a transposed
  * bf16 copy of a Linear weight so that the input-gradient GEMM of autograd (the dy @ W of nn.Linear's backward,
  * reached from layers/transformers.py:43-54 and layers/attention.py:36-59) reads both operands K-major. */
@@ -321,11 +332,17 @@ int vitk_dwconv_bwd(const void* dy, const void* x, const void* w, void* dx, floa
 /* im2col for the overlapping conv token embedding (layers/embeddings.py:21): x NCHW -> cols [B*Ho*Wo, C*ks*ks]
  * (the convolution itself is vitk_gemm on cols) and col2im (scatter-add) for its input gradient.
  * With tokens_in != 0 the input is token-major [B, H*W, C] (the layout CvT blocks produce), so the
- * 'b (h w) c -> b c h w' rearrange of models/cvt.py:91,98 is folded into the gather. */
+ * 'b (h w) c -> b c h w' rearrange of models/cvt.py:91,98 is folded into the gather.
+ * ld_cols >= C*ks*ks is the row stride of cols; im2col writes zeros into the columns past C*ks*ks, so that a K that is
+ * not a multiple of 8 (3 * 7 * 7 = 147 in the first CvT stage) reaches the bf16 GEMM already padded. */
 int vitk_im2col(const void* x, void* cols, int64_t B, int64_t C, int64_t H, int64_t W, int64_t ks, int64_t stride, int64_t pad,
-	int tokens_in, int dtype, void* stream);
+	int64_t ld_cols, int tokens_in, int dtype, void* stream);
 int vitk_col2im(const void* cols, void* dx, int64_t B, int64_t C, int64_t H, int64_t W, int64_t ks, int64_t stride, int64_t pad,
-	int tokens_in, int dtype, void* stream);
+	int64_t ld_cols, int tokens_in, int dtype, void* stream);
+/* dst[r, 0:cols] = src[r, 0:cols] converted to dst_dtype, dst[r, cols:ld_dst] = 0: the conv weight [C_out, C*ks*ks]
+ * (layers/embeddings.py:21) as the zero-padded K-major operand that goes with a padded cols matrix. */
+int vitk_pad_cols(const void* src, void* dst, int64_t rows, int64_t cols, int64_t ld_src, int64_t ld_dst, int src_dtype,
+	int dst_dtype, void* stream);
 /* BatchNorm over token-major activations x[rows, C] (nn.BatchNorm2d after the conv, layers/embeddings.py:22,26-27;
  * rows = B*Ho*Wo).  training: batch statistics (biased variance for normalisation, unbiased for the running
  * update with `momentum`), save_mean/save_rstd [C] float32 kept for the backward.  eval: running statistics. */

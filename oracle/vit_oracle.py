@@ -111,6 +111,14 @@ def dyt_fwd(x, alpha, gamma, beta):
 	return gamma * torch.tanh(alpha * x) + beta
 
 
+def dyt_bwd(dy, x, alpha, gamma):
+	"""Gradients of dyt_fwd: (dx, dalpha [same shape as alpha], dgamma, dbeta)."""
+	t = torch.tanh(alpha * x)
+	u = dy * gamma * (1.0 - t * t)
+	d = x.shape[-1]
+	return u * alpha, (u * x).sum().reshape(alpha.shape), (dy * t).reshape(-1, d).sum(0), dy.reshape(-1, d).sum(0)
+
+
 def act_fwd(u, kind):
 	"""layers/transformers.py:26-33: F.gelu is the exact erf form."""
 	if kind == "gelu":

@@ -115,6 +115,64 @@ def test_norm_modules_golden(gpu, dtype):
 			assert relerr(p.grad, c["grad/" + k]) < GTOL[dtype], (nm, k)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_dyt_golden(gpu, dtype):
+	"""DyT alone and a ViTBlock built with config.norm = DyT, against the reference's outputs and gradients."""
+	from vit_amd.layers import MHA, ViTBlock
+	from vit_amd.layers.norm import DyT
+	g, meta = load_golden("dyt")
+	c = sub(g, "mod")
+	mod = DyT(40).to(gpu)
+	mod.load_state_dict(sub(c, "sd"))
+	x = c["x"].to(gpu).to(dtype).requires_grad_(True)
+	y = mod(x)
+	y.backward(c["dy"].to(gpu).to(dtype))
+	assert y.dtype == dtype
+	assert relerr(y, c["y"]) < TOL[dtype]
+	assert relerr(x.grad, c["dx"]) < GTOL[dtype]
+	for k, p in mod.named_parameters():
+		assert relerr(p.grad, c["grad/" + k]) < GTOL[dtype], k
+	b = meta["block"]
+
+	class Cfg:
+		d_model = b["d_model"]; n_head = b["n_head"]; d_ff = b["d_ff"]; dropout = 0.0; activation = b["activation"]; norm = DyT
+		use_layer_scale = False; use_qk_norm = False; attention = MHA
+	c = sub(g, "blk")
+	blk = ViTBlock(Cfg()).to(gpu)
+	blk.load_state_dict(sub(c, "sd"), strict=True)
+	x = c["x"].to(gpu).requires_grad_(True)
+	with torch.autocast("cuda", dtype=torch.bfloat16, enabled=(dtype == torch.bfloat16)):
+		y, _ = blk(x)
+	y.float().backward(c["dy"].to(gpu))
+	assert relerr(y, c["y"]) < TOL[dtype]
+	assert relerr(x.grad, c["dx"]) < GTOL[dtype]
+	for k, p in blk.named_parameters():
+		assert relerr(p.grad, c["grad/" + k]) < GTOL[dtype], k
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("rows,d", [(197 * 64, 768), (1000, 200), (33, 4096), (17, 1023)])
+def test_dyt_kernels(gpu, dtype, rows, d):
+	"""The DyT kernels at model sizes, ragged widths and both access widths, against the oracle."""
+	from oracle import vit_oracle as O
+	from vit_amd import ops
+	gen = torch.Generator().manual_seed(rows + d)
+	x = (1.5 * torch.randn(rows, d, generator=gen)).to(dtype)
+	dy = torch.randn(rows, d, generator=gen).to(dtype)
+	al = torch.tensor([0.6])
+	ga = 1.0 + 0.3 * torch.randn(d, generator=gen)
+	be = 0.3 * torch.randn(d, generator=gen)
+	xg = x.to(gpu).requires_grad_(True)
+	pa, pg, pb = (t.to(gpu).requires_grad_(True) for t in (al, ga, be))
+	y = ops.DyTFn.apply(xg, pa, pg, pb)
+	y.backward(dy.to(gpu))
+	xd, dyd = x.double(), dy.double()
+	assert relerr(y, O.dyt_fwd(xd, al.double(), ga.double(), be.double())) < TOL[dtype]
+	dx, dal, dga, dbe = O.dyt_bwd(dyd, xd, al.double(), ga.double())
+	assert relerr(xg.grad, dx) < TOL[dtype]
+	assert relerr(pa.grad, dal) < 1e-3 and relerr(pg.grad, dga) < 1e-4 and relerr(pb.grad, dbe) < 1e-4  # float32 sums of rounded inputs
+
+
 def test_dropout_block_runs(gpu):
 	"""Training-mode dropout takes the unfused composition; it cannot match torch's RNG stream, so only sanity is checked:
 	finite outputs, gradients everywhere, and eval() equals the fused path."""

@@ -80,6 +80,16 @@ def test_norms():
 		assert relerr(dx, c["dx"]) < TOL and relerr(dw, c["grad/weight"]) < TOL
 
 
+def test_dyt():
+	"""DyT forward and explicit backward against the reference module's own outputs and autograd gradients."""
+	g, _ = load_golden("dyt")
+	c = sub(g, "mod")
+	al, ga, be = c["sd/alpha"], c["sd/gamma"], c["sd/beta"]
+	assert relerr(O.dyt_fwd(c["x"], al, ga, be), c["y"]) < TOL
+	dx, dal, dga, dbe = O.dyt_bwd(c["dy"], c["x"], al, ga)
+	assert relerr(dx, c["dx"]) < TOL and relerr(dal, c["grad/alpha"]) < TOL and relerr(dga, c["grad/gamma"]) < TOL and relerr(dbe, c["grad/beta"]) < TOL
+
+
 @pytest.mark.parametrize("case", ["dh64", "dh12", "dh24", "dh64_n65"])
 def test_mha(case):
 	g, meta = load_golden("mha")

@@ -111,11 +111,54 @@ def teacher_fixture(args):
 	save(args.out, "resnet20_teacher", arrays, {"kind": "teacher", "depth": 20, "num_classes": 10, "weights": "checkpoints/resnet20_cifar10.pth"})
 
 
+def dyt_fixture(args):
+	"""DyT (layers/norm.py:35-45 there) alone, and a ViTBlock built with config.norm = DyT (layers/vit.py:9-60): inputs,
+	parameters, outputs, every gradient, float32 on the CPU."""
+	from config import ViTConfig
+	from layers.norm import DyT
+	from layers.vit import ViTBlock
+	g = torch.Generator().manual_seed(77)
+	arrays = {}
+	m = DyT(40, init_alpha=0.7)
+	with torch.no_grad():
+		m.gamma.add_(0.3 * torch.randn(40, generator=g))
+		m.beta.add_(0.3 * torch.randn(40, generator=g))
+	x = (2.0 * torch.randn(3, 7, 40, generator=g)).requires_grad_(True)
+	y = m(x)
+	dy = torch.randn(y.shape, generator=g)
+	y.backward(dy)
+	arrays.update({"mod/x": np_(x), "mod/y": np_(y), "mod/dy": np_(dy), "mod/dx": np_(x.grad)})
+	for k, p_ in m.named_parameters():
+		arrays["mod/sd/" + k] = np_(p_)
+		arrays["mod/grad/" + k] = np_(p_.grad)
+	torch.manual_seed(9)
+	from layers.attention import MHA
+
+	class Cfg(ViTConfig):
+		d_model = 48; n_head = 4; d_ff = 96; norm = DyT; attention = MHA; activation = "gelu"; dropout = 0.0; use_layer_scale = False; use_qk_norm = False
+	blk = ViTBlock(Cfg())
+	with torch.no_grad():
+		for k, p_ in blk.named_parameters():
+			if "norm" in k:
+				p_.add_(0.2 * torch.randn(p_.shape, generator=g))
+	x = torch.randn(2, 9, 48, generator=g).requires_grad_(True)
+	out = blk(x)
+	yb = out[0] if isinstance(out, tuple) else out
+	dy = torch.randn(yb.shape, generator=g)
+	yb.backward(dy)
+	arrays.update({"blk/x": np_(x), "blk/y": np_(yb), "blk/dy": np_(dy), "blk/dx": np_(x.grad)})
+	for k, v in blk.state_dict().items():
+		arrays["blk/sd/" + k] = np_(v)
+	for k, p_ in blk.named_parameters():
+		arrays["blk/grad/" + k] = np_(p_.grad)
+	save(args.out, "dyt", arrays, {"kind": "dyt", "block": {"d_model": 48, "n_head": 4, "d_ff": 96, "activation": "gelu", "use_layer_scale": False}})
+
+
 def main():
 	ap = argparse.ArgumentParser()
 	ap.add_argument("--reference", default="/root/reference")
 	ap.add_argument("--out", default="tests/golden")
-	ap.add_argument("--only", default="", help="generate only this fixture (mbconv, teacher)")
+	ap.add_argument("--only", default="", help="generate only this fixture (mbconv, teacher, dyt)")
 	args = ap.parse_args()
 	sys.path.insert(0, args.reference)
 	os.makedirs(args.out, exist_ok=True)
@@ -126,6 +169,9 @@ def main():
 		return
 	if args.only == "teacher":
 		teacher_fixture(args)
+		return
+	if args.only == "dyt":
+		dyt_fixture(args)
 		return
 	from config import ViTConfig, CvTConfig
 	from layers.attention import MHA, ConvAttention

@@ -54,11 +54,14 @@ SIGNATURES = {
 	"vitk_layernorm_bwd": [P, P, P, P, P, P, P, P, P, I64, I64, I, P],
 	"vitk_rmsnorm_fwd": [P, P, P, P, P, P, I64, I64, FL, I, I, P],
 	"vitk_rmsnorm_bwd": [P, P, P, P, P, P, P, I64, I64, I, I, P],
+	"vitk_dyt_fwd": [P, P, P, P, P, I64, I64, I, P],
+	"vitk_dyt_bwd": [P, P, P, P, P, P, P, P, I64, I64, I, P],
 	"vitk_attention_fwd": [P, P, P, P, P, I64, I64, I64, I64, I64, I64, I64, I64, I64, FL, I, P],
 	"vitk_attention_bwd": [P, P, P, P, P, P, P, P, P, I64, I64, I64, I64, I64, I64, I64, I64, I64, I64, I64, I64, FL, P, I, P],
 	"vitk_attention_fwd_dropout": [P, P, P, P, P, I64, I64, I64, I64, I64, I64, I64, I64, I64, FL, FL, ctypes.c_uint64, I, P],
 	"vitk_attention_bwd_dropout": [P, P, P, P, P, P, P, P, P, I64, I64, I64, I64, I64, I64, I64, I64, I64, I64, I64, I64, FL, FL, ctypes.c_uint64, P, I, P],
 	"vitk_attention_bwd_noalloc": [P, P, P, P, P, P, P, P, P, I64, I64, I64, I64, I64, I64, I64, I64, I64, I64, I64, I64, FL, FL, ctypes.c_uint64, I, P],
+	"vitk_scale_by": [P, P, P, I64, I, P],
 	"vitk_cast": [P, P, I64, I, I, P],
 	"vitk_transpose": [P, P, I64, I64, I64, I64, I, P],
 	"vitk_transpose_batched": [P, P, I64, I, P],
@@ -87,8 +90,9 @@ SIGNATURES = {
 	"vitk_adamw_device_hparams": [P, P, P, P, P, P, I64, P, P, FL, P],
 	"vitk_dwconv_fwd": [P, P, P, I64, I64, I64, I64, I64, I64, I64, I, P],
 	"vitk_dwconv_bwd": [P, P, P, P, P, I64, I64, I64, I64, I64, I64, I64, I, P],
-	"vitk_im2col": [P, P, I64, I64, I64, I64, I64, I64, I64, I, I, P],
-	"vitk_col2im": [P, P, I64, I64, I64, I64, I64, I64, I64, I, I, P],
+	"vitk_im2col": [P, P, I64, I64, I64, I64, I64, I64, I64, I64, I, I, P],
+	"vitk_col2im": [P, P, I64, I64, I64, I64, I64, I64, I64, I64, I, I, P],
+	"vitk_pad_cols": [P, P, I64, I64, I64, I64, I, I, P],
 	"vitk_batchnorm_fwd": [P, P, P, P, P, P, P, P, I64, I64, FL, FL, I, I, P],
 	"vitk_batchnorm_bwd": [P, P, P, P, P, P, P, P, I64, I64, I, I, P],
 }

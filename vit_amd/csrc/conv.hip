@@ -115,12 +115,16 @@ __device__ __forceinline__ int64_t src_index(int tokens_in, int64_t b, int c, in
 
 template <typename T>
 __global__ __launch_bounds__(256) void im2col_kernel(const T* __restrict__ x, T* __restrict__ cols, int64_t B, int C, int H, int W, int ks, int stride, int pad,
-	int Ho, int Wo, int tokens_in) {
+	int Ho, int Wo, int tokens_in, int ld) {
 	const int K = C * ks * ks;
-	const int64_t n = B * Ho * Wo * K;
+	const int64_t n = B * Ho * Wo * ld;  // columns K .. ld - 1 of a row are written as zeros
 	for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-		const int k = (int)(i % K);
-		int64_t t = i / K;
+		const int k = (int)(i % ld);
+		int64_t t = i / ld;
+		if (k >= K) {
+			cols[i] = from_f32<T>(0.f);
+			continue;
+		}
 		const int wo = (int)(t % Wo);
 		t /= Wo;
 		const int ho = (int)(t % Ho);
@@ -136,8 +140,8 @@ __global__ __launch_bounds__(256) void im2col_kernel(const T* __restrict__ x, T*
 
 template <typename T>
 __global__ __launch_bounds__(256) void col2im_kernel(const T* __restrict__ cols, T* __restrict__ dx, int64_t B, int C, int H, int W, int ks, int stride, int pad,
-	int Ho, int Wo, int tokens_in) {
-	const int K = C * ks * ks;
+	int Ho, int Wo, int tokens_in, int ld) {
+	const int K = ld;  // row stride of cols (>= C * ks * ks)
 	const int64_t n = B * C * H * W;
 	for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
 		int c, h, w;
@@ -172,6 +176,17 @@ __global__ __launch_bounds__(256) void col2im_kernel(const T* __restrict__ cols,
 			}
 		}
 		dx[i] = from_f32<T>(acc);
+	}
+}
+
+// dst[r, 0:cols] = src[r, 0:cols] (converted), dst[r, cols:ld_dst] = 0
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void pad_cols_kernel(const TI* __restrict__ src, TO* __restrict__ dst, int64_t rows, int cols, int64_t ld_src, int ld_dst) {
+	const int64_t n = rows * ld_dst;
+	for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+		const int c = (int)(i % ld_dst);
+		const int64_t r = i / ld_dst;
+		dst[i] = c < cols ? from_f32<TO>(to_f32<TI>(src[r * ld_src + c])) : from_f32<TO>(0.f);
 	}
 }
 
@@ -323,27 +338,29 @@ extern "C" int vitk_dwconv_bwd(const void* dy, const void* x, const void* w, voi
 	});
 }
 
-extern "C" int vitk_im2col(const void* x, void* cols, int64_t B, int64_t C, int64_t H, int64_t W, int64_t ks, int64_t stride, int64_t pad, int tokens_in, int dtype,
-	void* stream) {
+extern "C" int vitk_im2col(const void* x, void* cols, int64_t B, int64_t C, int64_t H, int64_t W, int64_t ks, int64_t stride, int64_t pad, int64_t ld_cols,
+	int tokens_in, int dtype, void* stream) {
 	VITK_REQUIRE(x && cols, VITK_ERR_NULL);
 	int64_t Ho, Wo;
 	VITK_REQUIRE(B > 0 && C > 0 && conv_geom(H, W, ks, stride, pad, &Ho, &Wo), VITK_ERR_SHAPE);
+	VITK_REQUIRE(ld_cols >= C * ks * ks && ld_cols < (1ll << 31), VITK_ERR_SHAPE);
 	DISPATCH_T(dtype, {
-		hipLaunchKernelGGL((im2col_kernel<T>), dim3(vitk_stream_grid(B * Ho * Wo * C * ks * ks, 256)), dim3(256), 0, (hipStream_t)stream, (const T*)x, (T*)cols, B, (int)C,
-			(int)H, (int)W, (int)ks, (int)stride, (int)pad, (int)Ho, (int)Wo, tokens_in);
+		hipLaunchKernelGGL((im2col_kernel<T>), dim3(vitk_stream_grid(B * Ho * Wo * ld_cols, 256)), dim3(256), 0, (hipStream_t)stream, (const T*)x, (T*)cols, B, (int)C,
+			(int)H, (int)W, (int)ks, (int)stride, (int)pad, (int)Ho, (int)Wo, tokens_in, (int)ld_cols);
 		VITK_CHECK_LAUNCH();
 		return VITK_OK;
 	});
 }
 
-extern "C" int vitk_col2im(const void* cols, void* dx, int64_t B, int64_t C, int64_t H, int64_t W, int64_t ks, int64_t stride, int64_t pad, int tokens_in, int dtype,
-	void* stream) {
+extern "C" int vitk_col2im(const void* cols, void* dx, int64_t B, int64_t C, int64_t H, int64_t W, int64_t ks, int64_t stride, int64_t pad, int64_t ld_cols,
+	int tokens_in, int dtype, void* stream) {
 	VITK_REQUIRE(cols && dx, VITK_ERR_NULL);
 	int64_t Ho, Wo;
 	VITK_REQUIRE(B > 0 && C > 0 && conv_geom(H, W, ks, stride, pad, &Ho, &Wo), VITK_ERR_SHAPE);
+	VITK_REQUIRE(ld_cols >= C * ks * ks && ld_cols < (1ll << 31), VITK_ERR_SHAPE);
 	DISPATCH_T(dtype, {
 		hipLaunchKernelGGL((col2im_kernel<T>), dim3(vitk_stream_grid(B * C * H * W, 256)), dim3(256), 0, (hipStream_t)stream, (const T*)cols, (T*)dx, B, (int)C, (int)H,
-			(int)W, (int)ks, (int)stride, (int)pad, (int)Ho, (int)Wo, tokens_in);
+			(int)W, (int)ks, (int)stride, (int)pad, (int)Ho, (int)Wo, tokens_in, (int)ld_cols);
 		VITK_CHECK_LAUNCH();
 		return VITK_OK;
 	});
@@ -398,4 +415,23 @@ extern "C" int vitk_batchnorm_bwd(const void* dy, const void* x, const float* ga
 		VITK_CHECK_LAUNCH();
 		return VITK_OK;
 	});
+}
+
+extern "C" int vitk_pad_cols(const void* src, void* dst, int64_t rows, int64_t cols, int64_t ld_src, int64_t ld_dst, int src_dtype, int dst_dtype, void* stream) {
+	VITK_REQUIRE(src && dst, VITK_ERR_NULL);
+	VITK_REQUIRE(rows > 0 && cols > 0 && ld_src >= cols && ld_dst >= cols && ld_dst < (1ll << 31), VITK_ERR_SHAPE);
+	const dim3 grid(vitk_stream_grid(rows * ld_dst, 256));
+	hipStream_t st = (hipStream_t)stream;
+	if (src_dtype == VITK_F32 && dst_dtype == VITK_F32)
+		hipLaunchKernelGGL((pad_cols_kernel<float, float>), grid, dim3(256), 0, st, (const float*)src, (float*)dst, rows, (int)cols, ld_src, (int)ld_dst);
+	else if (src_dtype == VITK_F32 && dst_dtype == VITK_BF16)
+		hipLaunchKernelGGL((pad_cols_kernel<float, bf16_t>), grid, dim3(256), 0, st, (const float*)src, (bf16_t*)dst, rows, (int)cols, ld_src, (int)ld_dst);
+	else if (src_dtype == VITK_BF16 && dst_dtype == VITK_BF16)
+		hipLaunchKernelGGL((pad_cols_kernel<bf16_t, bf16_t>), grid, dim3(256), 0, st, (const bf16_t*)src, (bf16_t*)dst, rows, (int)cols, ld_src, (int)ld_dst);
+	else if (src_dtype == VITK_BF16 && dst_dtype == VITK_F32)
+		hipLaunchKernelGGL((pad_cols_kernel<bf16_t, float>), grid, dim3(256), 0, st, (const bf16_t*)src, (float*)dst, rows, (int)cols, ld_src, (int)ld_dst);
+	else
+		return VITK_ERR_DTYPE;
+	VITK_CHECK_LAUNCH();
+	return VITK_OK;
 }

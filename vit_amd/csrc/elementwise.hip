@@ -492,6 +492,20 @@ extern "C" int vitk_transpose(const void* x, void* y, int64_t rows, int64_t cols
 	});
 }
 
+struct ScaleByDev {
+	const float* g;
+	__device__ float operator()(float a, float, int64_t) const { return a * g[0]; }
+};
+
+extern "C" int vitk_scale_by(const void* x, const float* g, void* y, int64_t n, int dtype, void* stream) {
+	VITK_REQUIRE(x && g && y, VITK_ERR_NULL);
+	VITK_REQUIRE(n >= 0, VITK_ERR_SHAPE);
+	hipStream_t st = (hipStream_t)stream;
+	if (dtype == VITK_F32) return launch_map2<float, float, float>(x, nullptr, y, n, ScaleByDev{g}, st);
+	if (dtype == VITK_BF16) return launch_map2<bf16_t, float, bf16_t>(x, nullptr, y, n, ScaleByDev{g}, st);
+	return VITK_ERR_DTYPE;
+}
+
 extern "C" int vitk_cast(const void* src, void* dst, int64_t n, int src_dtype, int dst_dtype, void* stream) {
 	VITK_REQUIRE(src && dst, VITK_ERR_NULL);
 	VITK_REQUIRE(n >= 0, VITK_ERR_SHAPE);

@@ -225,6 +225,120 @@ __global__ __launch_bounds__(BWD_THREADS) void norm_bwd_kernel(const T* __restri
 	}
 }
 
+// ---- DyT (layers/norm.py:35-45): y = gamma * tanh(alpha * x) + beta, alpha a learned scalar ----------------------------
+// Elementwise and bandwidth-bound.  Thread t of a workgroup owns the column chunks t, t + 256, ... (at most DYT_CH of
+// VEC columns each) and walks the rows of its workgroup's slab, so gamma / beta and the column sums of the backward
+// stay in registers; a workgroup ends with one float atomic per column (and one for alpha).
+constexpr int DYT_CH = 4;
+
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void dyt_fwd_kernel(const T* __restrict__ x, const float* __restrict__ alpha, const float* __restrict__ gamma,
+	const float* __restrict__ beta, T* __restrict__ y, int64_t rows, int d) {
+	const int nchunk = d / VEC;
+	const float al = alpha[0];
+	float ga[DYT_CH][VEC], be[DYT_CH][VEC];
+#pragma unroll
+	for (int k = 0; k < DYT_CH; ++k) {
+		const int c = threadIdx.x + 256 * k;
+		if (c < nchunk) {
+			load_vec<float, VEC>(gamma + c * VEC, ga[k]);
+			load_vec<float, VEC>(beta + c * VEC, be[k]);
+		}
+	}
+	for (int64_t row = blockIdx.x; row < rows; row += gridDim.x) {
+#pragma unroll
+		for (int k = 0; k < DYT_CH; ++k) {
+			const int c = threadIdx.x + 256 * k;
+			if (c < nchunk) {
+				float v[VEC], o[VEC];
+				load_vec<T, VEC>(x + row * d + c * VEC, v);
+#pragma unroll
+				for (int j = 0; j < VEC; ++j) o[j] = ga[k][j] * tanhf(al * v[j]) + be[k][j];
+				store_vec<T, VEC>(y + row * d + c * VEC, o);
+			}
+		}
+	}
+}
+
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void dyt_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x, const float* __restrict__ alpha,
+	const float* __restrict__ gamma, T* __restrict__ dx, float* dalpha, float* dgamma, float* dbeta, int64_t rows, int d) {
+	__shared__ float red[4];
+	const int nchunk = d / VEC;
+	const float al = alpha[0];
+	float ga[DYT_CH][VEC], accg[DYT_CH][VEC], accb[DYT_CH][VEC];
+	float acca = 0.f;
+#pragma unroll
+	for (int k = 0; k < DYT_CH; ++k) {
+		const int c = threadIdx.x + 256 * k;
+#pragma unroll
+		for (int j = 0; j < VEC; ++j) accg[k][j] = accb[k][j] = ga[k][j] = 0.f;
+		if (c < nchunk) load_vec<float, VEC>(gamma + c * VEC, ga[k]);
+	}
+	for (int64_t row = blockIdx.x; row < rows; row += gridDim.x) {
+#pragma unroll
+		for (int k = 0; k < DYT_CH; ++k) {
+			const int c = threadIdx.x + 256 * k;
+			if (c < nchunk) {
+				float v[VEC], g[VEC], o[VEC];
+				load_vec<T, VEC>(x + row * d + c * VEC, v);
+				load_vec<T, VEC>(dy + row * d + c * VEC, g);
+#pragma unroll
+				for (int j = 0; j < VEC; ++j) {
+					const float t = tanhf(al * v[j]);
+					const float u = g[j] * ga[k][j] * (1.f - t * t);  // d loss / d (alpha x)
+					accg[k][j] += g[j] * t;
+					accb[k][j] += g[j];
+					acca += u * v[j];
+					o[j] = u * al;
+				}
+				store_vec<T, VEC>(dx + row * d + c * VEC, o);
+			}
+		}
+	}
+#pragma unroll
+	for (int k = 0; k < DYT_CH; ++k) {
+		const int c = threadIdx.x + 256 * k;
+		if (c < nchunk) {
+#pragma unroll
+			for (int j = 0; j < VEC; ++j) {
+				atomicAdd(&dgamma[c * VEC + j], accg[k][j]);
+				atomicAdd(&dbeta[c * VEC + j], accb[k][j]);
+			}
+		}
+	}
+	acca = wave_sum(acca);
+	if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acca;
+	__syncthreads();
+	if (threadIdx.x == 0) atomicAdd(dalpha, red[0] + red[1] + red[2] + red[3]);
+}
+
+template <typename T, int VEC>
+int launch_dyt(const void* dy, const void* x, const float* alpha, const float* gamma, const float* beta, void* out, float* dalpha, float* dgamma, float* dbeta,
+	int64_t rows, int d, hipStream_t st) {
+	const int grid = (int)std::min<int64_t>(rows, 1024);
+	if (dy == nullptr)
+		hipLaunchKernelGGL((dyt_fwd_kernel<T, VEC>), dim3(grid), dim3(256), 0, st, (const T*)x, alpha, gamma, beta, (T*)out, rows, d);
+	else
+		hipLaunchKernelGGL((dyt_bwd_kernel<T, VEC>), dim3(grid), dim3(256), 0, st, (const T*)dy, (const T*)x, alpha, gamma, (T*)out, dalpha, dgamma, dbeta, rows, d);
+	VITK_CHECK_LAUNCH();
+	return VITK_OK;
+}
+
+int run_dyt(const void* dy, const void* x, const float* alpha, const float* gamma, const float* beta, void* out, float* dalpha, float* dgamma, float* dbeta,
+	int64_t rows, int64_t d, int dtype, hipStream_t st) {
+	VITK_REQUIRE(rows > 0 && d > 0, VITK_ERR_SHAPE);
+	VITK_REQUIRE(dtype == VITK_F32 || dtype == VITK_BF16, VITK_ERR_DTYPE);
+	const bool vec = d % 4 == 0 && vitk_aligned(x, 16) && vitk_aligned(out, 16) && (dy == nullptr || vitk_aligned(dy, 16)) && vitk_aligned(gamma, 16) &&
+		(beta == nullptr || vitk_aligned(beta, 16));
+	VITK_REQUIRE(d <= (vec ? 4 : 1) * 256 * DYT_CH, VITK_ERR_UNSUPPORTED);
+	if (dtype == VITK_F32)
+		return vec ? launch_dyt<float, 4>(dy, x, alpha, gamma, beta, out, dalpha, dgamma, dbeta, rows, (int)d, st)
+				   : launch_dyt<float, 1>(dy, x, alpha, gamma, beta, out, dalpha, dgamma, dbeta, rows, (int)d, st);
+	return vec ? launch_dyt<bf16_t, 4>(dy, x, alpha, gamma, beta, out, dalpha, dgamma, dbeta, rows, (int)d, st)
+			   : launch_dyt<bf16_t, 1>(dy, x, alpha, gamma, beta, out, dalpha, dgamma, dbeta, rows, (int)d, st);
+}
+
 struct NormArgs {
 	const void *x, *res, *dy, *dres;
 	const float *gamma, *beta, *mean_in, *rstd_in;
@@ -337,4 +451,15 @@ extern "C" int vitk_rmsnorm_bwd(const void* dy, const void* x, const float* weig
 	a.dy = dy; a.x = x; a.gamma = weight; a.rstd_in = rstd; a.dres = dres; a.dx = dx; a.dgamma = dweight;
 	a.rows = rows; a.d = (int)d; a.offset = unit_offset ? 1.f : 0.f;
 	return run<true, false>(a, dtype, (hipStream_t)stream);
+}
+
+extern "C" int vitk_dyt_fwd(const void* x, const float* alpha, const float* gamma, const float* beta, void* y, int64_t rows, int64_t d, int dtype, void* stream) {
+	VITK_REQUIRE(x && alpha && gamma && beta && y, VITK_ERR_NULL);
+	return run_dyt(nullptr, x, alpha, gamma, beta, y, nullptr, nullptr, nullptr, rows, d, dtype, (hipStream_t)stream);
+}
+
+extern "C" int vitk_dyt_bwd(const void* dy, const void* x, const float* alpha, const float* gamma, void* dx, float* dalpha, float* dgamma, float* dbeta,
+	int64_t rows, int64_t d, int dtype, void* stream) {
+	VITK_REQUIRE(dy && x && alpha && gamma && dx && dalpha && dgamma && dbeta, VITK_ERR_NULL);
+	return run_dyt(dy, x, alpha, gamma, nullptr, dx, dalpha, dgamma, dbeta, rows, d, dtype, (hipStream_t)stream);
 }

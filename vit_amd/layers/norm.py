@@ -35,7 +35,9 @@ class LayerNorm(nn.LayerNorm):
 
 
 def apply_norm(mod, x):
-	"""Run `mod` (RMSNorm, LayerNorm or a stock nn.LayerNorm built by config.norm) on the vitk kernels."""
+	"""Run `mod` (RMSNorm, LayerNorm, DyT or a stock nn.LayerNorm built by config.norm) on the vitk kernels."""
+	if isinstance(mod, DyT):
+		return mod(x)
 	kind, w, b, eps, off = norm_spec(mod)
 	return ops.NormFn.apply(x, w, b, kind, eps, off)
 
@@ -48,12 +50,13 @@ def norm_spec(mod):
 		if len(mod.normalized_shape) != 1 or mod.weight is None or mod.bias is None:
 			raise NotImplementedError("LayerNorm over the last dimension with affine parameters only")
 		return "layernorm", mod.weight, mod.bias, mod.eps, False
-	raise NotImplementedError(f"config.norm={type(mod).__name__} has no MI355X kernel (supported: LayerNorm, RMSNorm)")
+	raise NotImplementedError(f"config.norm={type(mod).__name__} has no fused-block form (LayerNorm and RMSNorm have; DyT runs module by module)")
 
 
 class DyT(nn.Module):
-	"""Dynamic tanh 'norm': gamma * tanh(alpha * x) + beta.  Kept for import compatibility with
-	the reference's config module; it is not on the accelerated path."""
+	"""Dynamic tanh 'norm' (layers/norm.py:35-45 of the reference): gamma * tanh(alpha * x) + beta with a learned scalar
+	alpha, one bandwidth-bound kernel each way.  The result has the dtype of x (the reference's float32 parameters promote
+	it to float32; the Linear that consumes it under autocast rounds it to bfloat16 either way)."""
 
 	def __init__(self, C, init_alpha=0.5):
 		super().__init__()
@@ -62,7 +65,7 @@ class DyT(nn.Module):
 		self.beta = nn.Parameter(torch.zeros(C))
 
 	def forward(self, x):
-		raise NotImplementedError("DyT has no MI355X kernel in this build")
+		return ops.DyTFn.apply(x, self.alpha, self.gamma, self.beta)
 
 
 class QKNorm(nn.Module):

@@ -11,7 +11,7 @@ import torch.nn as nn
 from .. import ops
 from .attention import MHA, QuadrangleAttention
 from .dropout import Dropout
-from .norm import apply_norm, norm_spec
+from .norm import DyT, apply_norm, norm_spec
 from .transformers import FeedForward
 
 
@@ -39,7 +39,7 @@ class ViTBlock(nn.Module):
 
 	def _fusable(self):
 		# with active dropout the fused node covers the block without LayerScale (the reference's default)
-		if not isinstance(self.attn, MHA):
+		if not isinstance(self.attn, MHA) or isinstance(self.attn_norm, DyT) or isinstance(self.ff_norm, DyT):
 			return False
 		if self.attn_layer_scale is None and self.ff_layer_scale is None:
 			return True

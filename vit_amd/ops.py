@@ -99,6 +99,24 @@ def weight_as(w, dtype):
 	return out
 
 
+def weight_padded(w, dtype, rows, cols, ld):
+	"""The parameter `w` viewed as [rows, cols], in `dtype`, with rows of `ld` >= cols elements (zeros behind the data): one
+	kernel, cached until the parameter is modified in place."""
+	if ld == cols:
+		return weight_as(w, dtype).reshape(rows, cols)
+	key = (w._version, dtype, w.data_ptr(), ld)
+	hit = _cast_cache.get((id(w), "pad"))
+	if hit is not None and hit[0]() is w and hit[1] == key:
+		return hit[2]
+	src = w.detach()
+	assert src.is_contiguous() and src.numel() == rows * cols
+	out = torch.empty((rows, ld), dtype=dtype, device=w.device)
+	L.check(L.load().vitk_pad_cols(L.ptr(src), L.ptr(out), rows, cols, cols, ld, L.dtype_code(src.dtype), L.dtype_code(dtype), L.stream()))
+	k = (id(w), "pad")
+	_cast_cache[k] = (weakref.ref(w, lambda _r, k=k, d=_cast_cache: d.pop(k, None)), key, out)
+	return out
+
+
 def transpose(x):
 	"""Contiguous transpose of a 2-D tensor through vitk_transpose."""
 	assert x.dim() == 2 and x.stride(1) == 1
@@ -537,6 +555,37 @@ class NormFn(torch.autograd.Function):
 		return dx, sk.ret("w", dw), sk.ret("b", db), None, None, None
 
 
+class DyTFn(torch.autograd.Function):
+	"""gamma * tanh(alpha * x) + beta over the last dimension (layers/norm.py:35-45), result in the dtype of x."""
+
+	@staticmethod
+	def forward(ctx, x, alpha, gamma, beta):
+		L.require_gpu(x, gamma)
+		dt = x.dtype if x.dtype in (torch.float32, torch.bfloat16) else torch.float32
+		x2 = _flat(cast(x, dt))
+		y = torch.empty_like(x2)
+		L.check(L.load().vitk_dyt_fwd(L.ptr(x2), L.ptr(f32(alpha)), L.ptr(f32(gamma)), L.ptr(f32(beta)), L.ptr(y), x2.shape[0], x2.shape[1],
+			L.dtype_code(dt), L.stream()))
+		ctx.save_for_backward(x2, alpha, gamma)
+		ctx.meta = (x.shape, x.dtype)
+		return y.reshape(x.shape)
+
+	@staticmethod
+	def backward(ctx, dy):
+		x2, alpha, gamma = ctx.saved_tensors
+		xshape, xdtype = ctx.meta
+		dy2 = _flat(cast(dy, x2.dtype))
+		dx = torch.empty_like(x2)
+		d = x2.shape[1]
+		acc = torch.zeros(2 * d + 1, dtype=torch.float32, device=x2.device)  # [dgamma | dbeta | dalpha]
+		L.check(L.load().vitk_dyt_bwd(L.ptr(dy2), L.ptr(x2), L.ptr(f32(alpha)), L.ptr(f32(gamma)), L.ptr(dx), L.ptr(acc[2 * d:]), L.ptr(acc), L.ptr(acc[d:]),
+			x2.shape[0], d, L.dtype_code(x2.dtype), L.stream()))
+		dx = dx.reshape(xshape)
+		if dx.dtype != xdtype:
+			dx = cast(dx, xdtype)
+		return dx, acc[2 * d:].reshape(alpha.shape).to(alpha.dtype), acc[:d].to(gamma.dtype), acc[d:2 * d].to(gamma.dtype)
+
+
 def _ffn_forward(x2, w1, b1, w2, b2, act, gated, residual=None, gamma=None, drop1=(0.0, 0), drop_out=()):
 	"""fc_in -> act / gate*act -> dropout1 -> fc_out (layers/transformers.py:45-57).  Returns (y, u, a) with `a` the
 	input of fc_out (after dropout1: in the activation epilogue of fc_in, or in place after the gating kernel).
@@ -881,7 +930,7 @@ class CeKdLossFn(torch.autograd.Function):
 	@staticmethod
 	def backward(ctx, g):
 		(dlogits,) = ctx.saved_tensors
-		return dlogits * g.to(dlogits.dtype), None, None, None, None, None
+		return scale_by(dlogits, g), None, None, None, None, None
 
 
 class DeitDualLossFn(torch.autograd.Function):
@@ -909,8 +958,10 @@ class DeitDualLossFn(torch.autograd.Function):
 
 
 def scale_by(t, g):
-	"""t * g for the scalar upstream gradient g of a loss; g == 1 (loss.backward()) costs nothing."""
-	return t * g.to(t.dtype)
+	"""t * g for the scalar upstream gradient g (a 0-dim device tensor) of a loss."""
+	out = torch.empty_like(t)
+	L.check(L.load().vitk_scale_by(L.ptr(t), L.ptr(cast(g.reshape(1), torch.float32)), L.ptr(out), t.numel(), L.dtype_code(t.dtype), L.stream()))
+	return out
 
 
 def deit_dual_loss(logits_cls, logits_dist, labels, teacher, alpha=0.5, tau=1.0, label_smoothing=0.0):
@@ -1066,16 +1117,13 @@ class ConvEmbedFn(torch.autograd.Function):
 		K = C * ks * ks
 		rows = Bn * Ho * Wo
 		dtc = L.dtype_code(dt)
-		cols = torch.empty((rows, K), dtype=dt, device=x.device)
-		L.check(lib.vitk_im2col(L.ptr(xc), L.ptr(cols), Bn, C, H, W, ks, stride, pad, tokens_in, dtc, L.stream()))
-		w2 = weight_as(conv_w, dt).reshape(Cout, K)
-		if dt == torch.bfloat16 and K % 8 != 0:
-			# K = 3 * 7 * 7 = 147 for the first CvT stage: zero columns up to a multiple of 8 put all three GEMMs of this layer
-			# on the bf16 MFMA kernels (the weight gradient is a [64, 147] x 16384-deep product: 3 workgroups and no K split
-			# on the generic kernel)
-			Kp = (K + 7) // 8 * 8
-			cols = torch.nn.functional.pad(cols, (0, Kp - K))
-			w2 = torch.nn.functional.pad(w2, (0, Kp - K))
+		# K = 3 * 7 * 7 = 147 for the first CvT stage: zero columns up to a multiple of 8 (written by the gather itself, and a
+		# zero-padded copy of the weight) put all three GEMMs of this layer on the bf16 MFMA kernels (the weight gradient is a
+		# [64, 147] x 16384-deep product: 3 workgroups and no K split on the generic kernel)
+		Kp = (K + 7) // 8 * 8 if dt == torch.bfloat16 else K
+		cols = torch.empty((rows, Kp), dtype=dt, device=x.device)
+		L.check(lib.vitk_im2col(L.ptr(xc), L.ptr(cols), Bn, C, H, W, ks, stride, pad, Kp, tokens_in, dtc, L.stream()))
+		w2 = weight_padded(conv_w, dt, Cout, K, Kp)
 		y0 = linear_fwd(cols, w2)
 		y = torch.empty_like(y0)
 		save_mean = torch.empty(Cout, dtype=torch.float32, device=x.device)
@@ -1106,14 +1154,9 @@ class ConvEmbedFn(torch.autograd.Function):
 		dw = (dw[:, :K] if Kp != K else dw).reshape(conv_w.shape)
 		dx = None
 		if ctx.needs_input_grad[0]:
-			w2 = weight_as(conv_w, dt).reshape(Cout, -1)
-			if Kp != K:
-				w2 = torch.nn.functional.pad(w2, (0, Kp - K))
-			dcols = linear_dgrad(dy0, w2)
-			if Kp != K:
-				dcols = dcols[:, :K].contiguous()
+			dcols = linear_dgrad(dy0, weight_padded(conv_w, dt, Cout, K, Kp))
 			dx = torch.empty(xshape, dtype=dt, device=dy.device)
-			L.check(lib.vitk_col2im(L.ptr(dcols), L.ptr(dx), Bn, C, H, W, ks, stride, pad, tokens_in, dtc, L.stream()))
+			L.check(lib.vitk_col2im(L.ptr(dcols), L.ptr(dx), Bn, C, H, W, ks, stride, pad, Kp, tokens_in, dtc, L.stream()))
 			if dx.dtype != xdtype:
 				dx = cast(dx, xdtype)
 		return dx, grad_as(dw, conv_w), grad_as(dgamma, bn_w), grad_as(dbeta, bn_b), None, None, None
@@ -1223,7 +1266,7 @@ class MBConvFn(torch.autograd.Function):
 			Bn, Cin, H, W = xc.shape
 			R = Bn * H * W
 			t0 = torch.empty((R, Cin), dtype=dt, device=x.device)
-			L.check(lib.vitk_im2col(L.ptr(xc), L.ptr(t0), Bn, Cin, H, W, 1, 1, 0, 0, dtc, L.stream()))
+			L.check(lib.vitk_im2col(L.ptr(xc), L.ptr(t0), Bn, Cin, H, W, 1, 1, 0, Cin, 0, dtc, L.stream()))
 		else:
 			Bn, S, Cin = xc.shape
 			H, W = hw
@@ -1256,7 +1299,7 @@ class MBConvFn(torch.autograd.Function):
 		Ho, Wo = _conv_out(H, 3, stride, 1), _conv_out(W, 3, stride, 1)
 		if hw is None:
 			y = torch.empty((Bn, Cout, Ho, Wo), dtype=dt, device=x.device)
-			L.check(lib.vitk_col2im(L.ptr(n3), L.ptr(y), Bn, Cout, Ho, Wo, 1, 1, 0, 0, dtc, L.stream()))
+			L.check(lib.vitk_col2im(L.ptr(n3), L.ptr(y), Bn, Cout, Ho, Wo, 1, 1, 0, Cout, 0, dtc, L.stream()))
 		else:
 			y = n3.reshape(Bn, Ho * Wo, Cout)
 		ctx.save_for_backward(t0, h1, n1, a1, h2, n2, a2, h3, m1, r1, m2, r2, m3, r3, w1, wd, w3, g1, g2, g3)
@@ -1274,7 +1317,7 @@ class MBConvFn(torch.autograd.Function):
 		dyc = cast(dy, dt).contiguous()
 		if hw is None:
 			d3 = torch.empty((Bn * Ho * Wo, Cout), dtype=dt, device=dy.device)
-			L.check(lib.vitk_im2col(L.ptr(dyc), L.ptr(d3), Bn, Cout, Ho, Wo, 1, 1, 0, 0, dtc, L.stream()))
+			L.check(lib.vitk_im2col(L.ptr(dyc), L.ptr(d3), Bn, Cout, Ho, Wo, 1, 1, 0, Cout, 0, dtc, L.stream()))
 		else:
 			d3 = dyc.reshape(Bn * Ho * Wo, Cout)
 
@@ -1306,7 +1349,7 @@ class MBConvFn(torch.autograd.Function):
 				dt0 = scale_residual(dt0, d3, None)
 			if hw is None:
 				dx = torch.empty(xshape, dtype=dt, device=dy.device)
-				L.check(lib.vitk_col2im(L.ptr(dt0), L.ptr(dx), Bn, Cin, H, W, 1, 1, 0, 0, dtc, L.stream()))
+				L.check(lib.vitk_col2im(L.ptr(dt0), L.ptr(dx), Bn, Cin, H, W, 1, 1, 0, Cin, 0, dtc, L.stream()))
 			else:
 				dx = dt0.reshape(xshape)
 			if dx.dtype != xdtype:
@@ -1362,7 +1405,7 @@ class ConvTokensFn(torch.autograd.Function):
 		assert K % 8 == 0 or dt == torch.float32, "bf16: C * k * k must be a multiple of 8"
 		dtc = L.dtype_code(dt)
 		cols = torch.empty((Bn * Ho * Wo, K), dtype=dt, device=x.device)
-		L.check(lib.vitk_im2col(L.ptr(xc), L.ptr(cols), Bn, C, H, W, ks, stride, pad, tokens_in, dtc, L.stream()))
+		L.check(lib.vitk_im2col(L.ptr(xc), L.ptr(cols), Bn, C, H, W, ks, stride, pad, K, tokens_in, dtc, L.stream()))
 		y = linear_fwd(cols, weight_as(w, dt).reshape(Cout, K), f32(b))
 		ctx.save_for_backward(cols, w)
 		ctx.meta = (x.shape, x.dtype, b, cfg, dt, (Bn, C, H, W, tokens_in))
@@ -1379,7 +1422,7 @@ class ConvTokensFn(torch.autograd.Function):
 		if ctx.needs_input_grad[0]:
 			dcols = linear_dgrad(dy2, weight_as(w, dt).reshape(Cout, -1))
 			dx = torch.empty(xshape, dtype=dt, device=dy.device)
-			L.check(L.load().vitk_col2im(L.ptr(dcols), L.ptr(dx), Bn, C, H, W, ks, stride, pad, tokens_in, L.dtype_code(dt), L.stream()))
+			L.check(L.load().vitk_col2im(L.ptr(dcols), L.ptr(dx), Bn, C, H, W, ks, stride, pad, dcols.shape[1], tokens_in, L.dtype_code(dt), L.stream()))
 			if dx.dtype != xdtype:
 				dx = cast(dx, xdtype)
 		return dx, grad_as(dw.reshape(w.shape), w), grad_as(db, b), None
