@@ -107,6 +107,158 @@ __global__ __launch_bounds__(64 * DW_TY) void dwconv_bwd_dw_kernel(const T* __re
 	}
 }
 
+// ---- depthwise 3 x 3 in 16-byte channel groups ----------------------------------------------------------------------
+// The kernels above move one 2-byte element per lane and instruction; these own V = 16 bytes of channels per thread
+// (C % V == 0, 16-byte aligned tensors), keep the 9 x V taps in registers and walk one image row, so a wave moves 1 KiB
+// per instruction and neighbouring outputs find their shared inputs in the vector cache.  Thread = (image, row, channel
+// group), channel group fastest.
+template <typename T, int V>
+__device__ __forceinline__ void load_taps3(const T* __restrict__ w, int c0, float (&wt)[9][V]) {
+#pragma unroll
+	for (int j = 0; j < V; ++j)
+#pragma unroll
+		for (int t = 0; t < 9; ++t) wt[t][j] = to_f32<T>(w[(c0 + j) * 9 + t]);
+}
+
+template <typename T, int V>
+__global__ __launch_bounds__(256) void dwconv3_fwd_kernel(const T* __restrict__ x, const T* __restrict__ w, T* __restrict__ y, int64_t B, int H, int W, int C,
+	int stride, int pad, int Ho, int Wo) {
+	const int ncg = C / V;
+	const int64_t n = B * Ho * ncg;
+	const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	const int cg = (int)(i % ncg);
+	const int ho = (int)((i / ncg) % Ho);
+	const int64_t b = i / ((int64_t)ncg * Ho);
+	const int c0 = cg * V;
+	float wt[9][V];
+	load_taps3<T, V>(w, c0, wt);
+	const T* xb = x + b * H * W * C + c0;
+	T* yb = y + (b * Ho + ho) * (int64_t)Wo * C + c0;
+	for (int wo = 0; wo < Wo; ++wo) {
+		float acc[V];
+#pragma unroll
+		for (int j = 0; j < V; ++j) acc[j] = 0.f;
+#pragma unroll
+		for (int kh = 0; kh < 3; ++kh) {
+			const int h = ho * stride - pad + kh;
+			if (h < 0 || h >= H) continue;
+#pragma unroll
+			for (int kw = 0; kw < 3; ++kw) {
+				const int ww = wo * stride - pad + kw;
+				if (ww < 0 || ww >= W) continue;
+				float v[V];
+				load_vec<T, V>(xb + ((int64_t)h * W + ww) * C, v);
+#pragma unroll
+				for (int j = 0; j < V; ++j) acc[j] += v[j] * wt[kh * 3 + kw][j];
+			}
+		}
+		store_vec<T, V>(yb + (int64_t)wo * C, acc);
+	}
+}
+
+template <typename T, int V>
+__global__ __launch_bounds__(256) void dwconv3_bwd_dx_kernel(const T* __restrict__ dy, const T* __restrict__ w, T* __restrict__ dx, int64_t B, int H, int W, int C,
+	int stride, int pad, int Ho, int Wo) {
+	const int ncg = C / V;
+	const int64_t n = B * H * ncg;
+	const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	const int cg = (int)(i % ncg);
+	const int h = (int)((i / ncg) % H);
+	const int64_t b = i / ((int64_t)ncg * H);
+	const int c0 = cg * V;
+	float wt[9][V];
+	load_taps3<T, V>(w, c0, wt);
+	// the output rows this input row feeds, one per tap row (or none)
+	int hos[3];
+#pragma unroll
+	for (int kh = 0; kh < 3; ++kh) {
+		const int hn = h + pad - kh;
+		hos[kh] = (hn >= 0 && hn % stride == 0 && hn / stride < Ho) ? hn / stride : -1;
+	}
+	const T* gb = dy + b * Ho * Wo * C + c0;
+	T* db = dx + (b * H + h) * (int64_t)W * C + c0;
+	for (int ww = 0; ww < W; ++ww) {
+		float acc[V];
+#pragma unroll
+		for (int j = 0; j < V; ++j) acc[j] = 0.f;
+#pragma unroll
+		for (int kw = 0; kw < 3; ++kw) {
+			const int wn = ww + pad - kw;
+			if (wn < 0 || wn % stride != 0 || wn / stride >= Wo) continue;
+			const int wo = wn / stride;
+#pragma unroll
+			for (int kh = 0; kh < 3; ++kh) {
+				if (hos[kh] < 0) continue;
+				float v[V];
+				load_vec<T, V>(gb + ((int64_t)hos[kh] * Wo + wo) * C, v);
+#pragma unroll
+				for (int j = 0; j < V; ++j) acc[j] += v[j] * wt[kh * 3 + kw][j];
+			}
+		}
+		store_vec<T, V>(db + (int64_t)ww * C, acc);
+	}
+}
+
+// dw[c, kh, kw] += sum over (b, ho, wo) of dy * x.  Workgroup = 8 channel groups x 32 position lanes; a thread walks the
+// output positions lane, lane + 32 * gridDim.y, ... ; the position lanes combine through LDS and the workgroup issues
+// one float atomic per (channel, tap).
+template <typename T, int V>
+__global__ __launch_bounds__(256) void dwconv3_bwd_dw_kernel(const T* __restrict__ dy, const T* __restrict__ x, float* dw, int64_t B, int H, int W, int C, int stride,
+	int pad, int Ho, int Wo) {
+	__shared__ float red[32][8 * V + 1];
+	const int ncg = C / V;
+	const int cgl = threadIdx.x & 7, pl = threadIdx.x >> 3;
+	const int cg = blockIdx.x * 8 + cgl;
+	const int c0 = cg * V;
+	const int64_t npos = B * Ho * Wo;
+	float acc[9][V];
+#pragma unroll
+	for (int t = 0; t < 9; ++t)
+#pragma unroll
+		for (int j = 0; j < V; ++j) acc[t][j] = 0.f;
+	if (cg < ncg) {
+		for (int64_t p = (int64_t)blockIdx.y * 32 + pl; p < npos; p += (int64_t)gridDim.y * 32) {
+			const int wo = (int)(p % Wo);
+			const int ho = (int)((p / Wo) % Ho);
+			const int64_t b = p / ((int64_t)Wo * Ho);
+			float g[V];
+			load_vec<T, V>(dy + p * C + c0, g);
+#pragma unroll
+			for (int kh = 0; kh < 3; ++kh) {
+				const int h = ho * stride - pad + kh;
+				if (h < 0 || h >= H) continue;
+#pragma unroll
+				for (int kw = 0; kw < 3; ++kw) {
+					const int ww = wo * stride - pad + kw;
+					if (ww < 0 || ww >= W) continue;
+					float v[V];
+					load_vec<T, V>(x + ((b * H + h) * W + ww) * C + c0, v);
+#pragma unroll
+					for (int j = 0; j < V; ++j) acc[kh * 3 + kw][j] += g[j] * v[j];
+				}
+			}
+		}
+	}
+#pragma unroll
+	for (int t = 0; t < 9; ++t) {  // (unrolled: a runtime index into acc would move it to scratch memory)
+		__syncthreads();
+#pragma unroll
+		for (int j = 0; j < V; ++j) red[pl][cgl * V + j] = acc[t][j];
+		__syncthreads();
+		if (threadIdx.x < 8 * V) {
+			const int c = blockIdx.x * 8 * V + threadIdx.x;
+			if (c < C) {
+				float s = 0.f;
+#pragma unroll
+				for (int l = 0; l < 32; ++l) s += red[l][threadIdx.x];
+				atomicAdd(&dw[c * 9 + t], s);
+			}
+		}
+	}
+}
+
 // ---- im2col / col2im -----------------------------------------------------------------------------------------
 template <typename T>
 __device__ __forceinline__ int64_t src_index(int tokens_in, int64_t b, int c, int h, int w, int C, int H, int W) {
@@ -225,6 +377,121 @@ __global__ __launch_bounds__(256) void bn_colreduce_kernel(const T* __restrict__
 	}
 }
 
+// The same in 16-byte channel groups (C % V == 0): workgroup = 16 channel groups x 16 row lanes.
+template <typename T, int V, int MODE>
+__global__ __launch_bounds__(256) void bn_colreduce_vec_kernel(const T* __restrict__ x, const T* __restrict__ dy, const float* __restrict__ mean,
+	const float* __restrict__ rstd, float* out0, float* out1, int64_t rows, int C) {
+	__shared__ float red0[16][16 * V + 1], red1[16][16 * V + 1];
+	const int cgl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+	const int cg = blockIdx.x * 16 + cgl;
+	const int c0 = cg * V;
+	float a0[V], a1[V];
+#pragma unroll
+	for (int j = 0; j < V; ++j) a0[j] = a1[j] = 0.f;
+	if (c0 < C) {
+		float mu[V], rs[V];
+#pragma unroll
+		for (int j = 0; j < V; ++j) {
+			mu[j] = (MODE >= 1) ? mean[c0 + j] : 0.f;
+			rs[j] = (MODE == 2) ? rstd[c0 + j] : 0.f;
+		}
+		for (int64_t r = (int64_t)blockIdx.y * 16 + rl; r < rows; r += (int64_t)gridDim.y * 16) {
+			float v[V];
+			load_vec<T, V>(x + r * C + c0, v);
+			if (MODE == 0) {
+#pragma unroll
+				for (int j = 0; j < V; ++j) a0[j] += v[j];
+			} else if (MODE == 1) {
+#pragma unroll
+				for (int j = 0; j < V; ++j) a0[j] += (v[j] - mu[j]) * (v[j] - mu[j]);
+			} else {
+				float g[V];
+				load_vec<T, V>(dy + r * C + c0, g);
+#pragma unroll
+				for (int j = 0; j < V; ++j) {
+					a0[j] += g[j];
+					a1[j] += g[j] * (v[j] - mu[j]) * rs[j];
+				}
+			}
+		}
+	}
+#pragma unroll
+	for (int j = 0; j < V; ++j) {
+		red0[rl][cgl * V + j] = a0[j];
+		red1[rl][cgl * V + j] = a1[j];
+	}
+	__syncthreads();
+	if (threadIdx.x < 16 * V) {
+		const int c = blockIdx.x * 16 * V + threadIdx.x;
+		if (c < C) {
+			float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+			for (int l = 0; l < 16; ++l) {
+				s0 += red0[l][threadIdx.x];
+				s1 += red1[l][threadIdx.x];
+			}
+			atomicAdd(&out0[c], s0);
+			if (MODE == 2) atomicAdd(&out1[c], s1);
+		}
+	}
+}
+
+// Workgroup = 16 channel groups x 16 row lanes, as in the column reductions: a thread keeps its channels' constants in
+// registers and walks rows, so the per-channel parameters are read once per thread instead of once per 16 bytes of data.
+template <typename T, int V>
+__global__ __launch_bounds__(256) void bn_apply_vec_kernel(const T* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+	const float* __restrict__ mean, const float* __restrict__ rstd_or_var, T* __restrict__ y, int64_t rows, int C, float eps, int use_var) {
+	const int cg = blockIdx.x * 16 + (threadIdx.x & 15), rl = threadIdx.x >> 4;
+	const int c0 = cg * V;
+	if (c0 >= C) return;
+	float sc[V], sh[V];  // y = x * sc + sh
+#pragma unroll
+	for (int j = 0; j < V; ++j) {
+		const float rs = use_var ? rsqrtf(rstd_or_var[c0 + j] + eps) : rstd_or_var[c0 + j];
+		sc[j] = rs * gamma[c0 + j];
+		sh[j] = beta[c0 + j] - mean[c0 + j] * sc[j];
+	}
+	for (int64_t r = (int64_t)blockIdx.y * 16 + rl; r < rows; r += (int64_t)gridDim.y * 16) {
+		float v[V], o[V];
+		load_vec<T, V>(x + r * C + c0, v);
+#pragma unroll
+		for (int j = 0; j < V; ++j) o[j] = v[j] * sc[j] + sh[j];
+		store_vec<T, V>(y + r * C + c0, o);
+	}
+}
+
+// training: dx = A * dy - K * (x - mean) - A * dbeta / n with A = gamma * rstd, K = A * rstd * dgamma / n; eval: dx = A * dy
+template <typename T, int V>
+__global__ __launch_bounds__(256) void bn_bwd_apply_vec_kernel(const T* __restrict__ dy, const T* __restrict__ x, const float* __restrict__ gamma,
+	const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ dgamma, const float* __restrict__ dbeta, T* __restrict__ dx,
+	int64_t rows, int C, float inv_rows, int training) {
+	const int cg = blockIdx.x * 16 + (threadIdx.x & 15), rl = threadIdx.x >> 4;
+	const int c0 = cg * V;
+	if (c0 >= C) return;
+	float A[V], K[V], D[V], mu[V];
+#pragma unroll
+	for (int j = 0; j < V; ++j) {
+		A[j] = gamma[c0 + j] * rstd[c0 + j];
+		K[j] = training ? A[j] * rstd[c0 + j] * dgamma[c0 + j] * inv_rows : 0.f;
+		D[j] = training ? A[j] * dbeta[c0 + j] * inv_rows : 0.f;
+		mu[j] = mean[c0 + j];
+	}
+	for (int64_t r = (int64_t)blockIdx.y * 16 + rl; r < rows; r += (int64_t)gridDim.y * 16) {
+		float g[V], o[V];
+		load_vec<T, V>(dy + r * C + c0, g);
+		if (training) {
+			float v[V];
+			load_vec<T, V>(x + r * C + c0, v);
+#pragma unroll
+			for (int j = 0; j < V; ++j) o[j] = A[j] * g[j] - K[j] * (v[j] - mu[j]) - D[j];
+		} else {
+#pragma unroll
+			for (int j = 0; j < V; ++j) o[j] = A[j] * g[j];
+		}
+		store_vec<T, V>(dx + r * C + c0, o);
+	}
+}
+
 // sums -> mean (MODE 0) ; centred sums of squares -> rstd + running-stat update (MODE 1)
 template <int MODE>
 __global__ void bn_finalize_kernel(float* save_mean, float* save_rstd, float* running_mean, float* running_var, int64_t rows, int C, float eps, float momentum) {
@@ -283,6 +550,13 @@ inline dim3 colgrid(int64_t rows, int C) {
 	return dim3(gx, gy);
 }
 
+// grid of the 16-byte-group column reductions: x = blocks of 16 channel groups, y = row slabs (16 row lanes each)
+inline dim3 colgrid_vec(int64_t rows, int ngroups) {
+	const unsigned gx = (unsigned)vitk_cdiv(ngroups, 16);
+	const unsigned gy = (unsigned)std::max<int64_t>(1, std::min<int64_t>(vitk_cdiv(rows, 64), std::max<int64_t>(1, 2048 / gx)));
+	return dim3(gx, gy);
+}
+
 }  // namespace
 
 #define DISPATCH_T(dtype, ...)             \
@@ -310,6 +584,13 @@ extern "C" int vitk_dwconv_fwd(const void* x, const void* w, void* y, int64_t B,
 	int64_t Ho, Wo;
 	VITK_REQUIRE(B > 0 && C > 0 && conv_geom(H, W, ks, stride, pad, &Ho, &Wo), VITK_ERR_SHAPE);
 	DISPATCH_T(dtype, {
+		constexpr int V = VecOf<T>::N;
+		if (ks == 3 && C % V == 0 && vitk_aligned(x, 16) && vitk_aligned(y, 16)) {
+			hipLaunchKernelGGL((dwconv3_fwd_kernel<T, V>), dim3((unsigned)vitk_cdiv(B * Ho * (C / V), 256)), dim3(256), 0, (hipStream_t)stream, (const T*)x, (const T*)w, (T*)y,
+				B, (int)H, (int)W, (int)C, (int)stride, (int)pad, (int)Ho, (int)Wo);
+			VITK_CHECK_LAUNCH();
+			return VITK_OK;
+		}
 		hipLaunchKernelGGL((dwconv_fwd_kernel<T>), dim3(vitk_stream_grid(B * Ho * Wo * C, 256)), dim3(256), 0, (hipStream_t)stream, (const T*)x, (const T*)w, (T*)y, B,
 			(int)H, (int)W, (int)C, (int)ks, (int)stride, (int)pad, (int)Ho, (int)Wo);
 		VITK_CHECK_LAUNCH();
@@ -326,6 +607,18 @@ extern "C" int vitk_dwconv_bwd(const void* dy, const void* x, const void* w, voi
 	hipError_t e = hipMemsetAsync(dw, 0, (size_t)C * ks * ks * sizeof(float), st);
 	if (e != hipSuccess) return VITK_ERR_HIP - (int)e;
 	DISPATCH_T(dtype, {
+		constexpr int V = VecOf<T>::N;
+		if (ks == 3 && C % V == 0 && vitk_aligned(x, 16) && vitk_aligned(dy, 16) && vitk_aligned(dx, 16)) {
+			hipLaunchKernelGGL((dwconv3_bwd_dx_kernel<T, V>), dim3((unsigned)vitk_cdiv(B * H * (C / V), 256)), dim3(256), 0, st, (const T*)dy, (const T*)w, (T*)dx, B, (int)H,
+				(int)W, (int)C, (int)stride, (int)pad, (int)Ho, (int)Wo);
+			VITK_CHECK_LAUNCH();
+			const unsigned gx = (unsigned)vitk_cdiv(C / V, 8);
+			const unsigned gy = (unsigned)std::max<int64_t>(1, std::min<int64_t>(vitk_cdiv(B * Ho * Wo, 4 * 32), std::max<int64_t>(1, 1024 / gx)));
+			hipLaunchKernelGGL((dwconv3_bwd_dw_kernel<T, V>), dim3(gx, gy), dim3(256), 0, st, (const T*)dy, (const T*)x, dw, B, (int)H, (int)W, (int)C, (int)stride, (int)pad,
+				(int)Ho, (int)Wo);
+			VITK_CHECK_LAUNCH();
+			return VITK_OK;
+		}
 		hipLaunchKernelGGL((dwconv_bwd_dx_kernel<T>), dim3(vitk_stream_grid(B * H * W * C, 256)), dim3(256), 0, st, (const T*)dy, (const T*)w, (T*)dx, B, (int)H, (int)W,
 			(int)C, (int)ks, (int)stride, (int)pad, (int)Ho, (int)Wo);
 		VITK_CHECK_LAUNCH();
@@ -375,8 +668,13 @@ extern "C" int vitk_batchnorm_fwd(const void* x, const float* gamma, const float
 	if (!training) {
 		if (save_mean && save_rstd) hipLaunchKernelGGL(bn_eval_stats_kernel, dim3((unsigned)vitk_cdiv(C, 256)), dim3(256), 0, st, running_mean, running_var, save_mean, save_rstd, (int)C, eps);
 		DISPATCH_T(dtype, {
-			hipLaunchKernelGGL((bn_apply_kernel<T>), dim3(vitk_stream_grid(n, 256)), dim3(256), 0, st, (const T*)x, gamma, beta, running_mean, running_var, (T*)y, n, (int)C,
-				eps, 1);
+			constexpr int V = VecOf<T>::N;
+			if (C % V == 0 && vitk_aligned(x, 16) && vitk_aligned(y, 16))
+				hipLaunchKernelGGL((bn_apply_vec_kernel<T, V>), colgrid_vec(rows, (int)C / V), dim3(256), 0, st, (const T*)x, gamma, beta, running_mean, running_var, (T*)y, rows,
+					(int)C, eps, 1);
+			else
+				hipLaunchKernelGGL((bn_apply_kernel<T>), dim3(vitk_stream_grid(n, 256)), dim3(256), 0, st, (const T*)x, gamma, beta, running_mean, running_var, (T*)y, n, (int)C,
+					eps, 1);
 			VITK_CHECK_LAUNCH();
 			return VITK_OK;
 		});
@@ -388,6 +686,17 @@ extern "C" int vitk_batchnorm_fwd(const void* x, const float* gamma, const float
 	const dim3 cg = colgrid(rows, (int)C);
 	const unsigned fg = (unsigned)vitk_cdiv(C, 256);
 	DISPATCH_T(dtype, {
+		constexpr int V = VecOf<T>::N;
+		if (C % V == 0 && vitk_aligned(x, 16) && vitk_aligned(y, 16)) {
+			const dim3 vg = colgrid_vec(rows, (int)C / V);
+			hipLaunchKernelGGL((bn_colreduce_vec_kernel<T, V, 0>), vg, dim3(256), 0, st, (const T*)x, (const T*)nullptr, nullptr, nullptr, save_mean, nullptr, rows, (int)C);
+			hipLaunchKernelGGL((bn_finalize_kernel<0>), dim3(fg), dim3(256), 0, st, save_mean, save_rstd, running_mean, running_var, rows, (int)C, eps, momentum);
+			hipLaunchKernelGGL((bn_colreduce_vec_kernel<T, V, 1>), vg, dim3(256), 0, st, (const T*)x, (const T*)nullptr, save_mean, nullptr, save_rstd, nullptr, rows, (int)C);
+			hipLaunchKernelGGL((bn_finalize_kernel<1>), dim3(fg), dim3(256), 0, st, save_mean, save_rstd, running_mean, running_var, rows, (int)C, eps, momentum);
+			hipLaunchKernelGGL((bn_apply_vec_kernel<T, V>), vg, dim3(256), 0, st, (const T*)x, gamma, beta, save_mean, save_rstd, (T*)y, rows, (int)C, eps, 0);
+			VITK_CHECK_LAUNCH();
+			return VITK_OK;
+		}
 		hipLaunchKernelGGL((bn_colreduce_kernel<T, 0>), cg, dim3(256), 0, st, (const T*)x, (const T*)nullptr, nullptr, nullptr, save_mean, nullptr, rows, (int)C);
 		hipLaunchKernelGGL((bn_finalize_kernel<0>), dim3(fg), dim3(256), 0, st, save_mean, save_rstd, running_mean, running_var, rows, (int)C, eps, momentum);
 		hipLaunchKernelGGL((bn_colreduce_kernel<T, 1>), cg, dim3(256), 0, st, (const T*)x, (const T*)nullptr, save_mean, nullptr, save_rstd, nullptr, rows, (int)C);
@@ -409,6 +718,15 @@ extern "C" int vitk_batchnorm_bwd(const void* dy, const void* x, const float* ga
 	if (e != hipSuccess) return VITK_ERR_HIP - (int)e;
 	const dim3 cg = colgrid(rows, (int)C);
 	DISPATCH_T(dtype, {
+		constexpr int V = VecOf<T>::N;
+		if (C % V == 0 && vitk_aligned(x, 16) && vitk_aligned(dy, 16) && vitk_aligned(dx, 16)) {
+			hipLaunchKernelGGL((bn_colreduce_vec_kernel<T, V, 2>), colgrid_vec(rows, (int)C / V), dim3(256), 0, st, (const T*)x, (const T*)dy, save_mean, save_rstd, dbeta, dgamma,
+				rows, (int)C);
+			hipLaunchKernelGGL((bn_bwd_apply_vec_kernel<T, V>), colgrid_vec(rows, (int)C / V), dim3(256), 0, st, (const T*)dy, (const T*)x, gamma, save_mean, save_rstd, dgamma,
+				dbeta, (T*)dx, rows, (int)C, 1.0f / (float)rows, training);
+			VITK_CHECK_LAUNCH();
+			return VITK_OK;
+		}
 		hipLaunchKernelGGL((bn_colreduce_kernel<T, 2>), cg, dim3(256), 0, st, (const T*)x, (const T*)dy, save_mean, save_rstd, dbeta, dgamma, rows, (int)C);
 		hipLaunchKernelGGL((bn_bwd_apply_kernel<T>), dim3(vitk_stream_grid(n, 256)), dim3(256), 0, st, (const T*)dy, (const T*)x, gamma, save_mean, save_rstd, dgamma, dbeta,
 			(T*)dx, n, (int)C, 1.0f / (float)rows, training);
