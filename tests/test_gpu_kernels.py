@@ -236,7 +236,8 @@ def test_gemm_more_tiles_than_cus(gpu, act):
 
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("M,N,K", [(6400, 768, 512), (197 * 64, 768, 768), (197 * 32, 2304, 768), (6400 + 64, 256, 1024), (4099 * 8, 264, 320), (1000, 264, 192), (300, 130, 72), (197 * 8, 1000, 768),
-	(33280, 192, 576), (8000, 64, 192), (20000, 200, 136)])  # the last three: narrow layers over many rows (128 x 128 tiles, many K slices through scratch)
+	(33280, 192, 576), (8000, 64, 192), (20000, 200, 136),  # these three: narrow layers over many rows (many K slices through scratch)
+	(33280, 192, 192), (33280, 768, 192), (33792, 192, 768), (65536, 64, 256), (16384, 384, 192), (4096, 128, 64), (8192, 320, 448)])  # the weight gradients of the 32 x 32 models (layer widths 64 ... 768 over 4 k ... 65 k tokens)
 def test_wgrad_with_bias_grad(gpu, dtype, M, N, K):
 	"""dw = dy^T x together with db = column sums of dy (what autograd's addmm backward produces), on every GEMM path:
 	large tiles with split-K (column sums fused into the kernel; whole-tile shapes on the deep-pipeline kernel, also with a
