@@ -9,8 +9,11 @@ from conftest import load_golden, relerr, sub
 pytestmark = pytest.mark.gpu
 
 TOL = {torch.float32: 1e-4, torch.bfloat16: 2e-2}
-# gradients in bf16 accumulate rounding through the depth of the network
-GTOL = {torch.float32: 2e-4, torch.bfloat16: 4e-2}
+# gradients in bf16 accumulate rounding through the depth of the network: measured on the goldens here at most 1.2e-2 (ViT),
+# 2.3e-2 (MBConv, whose BatchNorms divide by batch statistics of rounded activations); the reference's own modules under
+# bfloat16 autocast on the CPU differ from their float32 run by 0.8 - 1.0e-2 on the same fixtures (tests/golden/ref_bf16_errors.json).
+# float32: measured at most 4e-6
+GTOL = {torch.float32: 1e-4, torch.bfloat16: 3e-2}
 
 
 def make_vit(c, gpu):
@@ -320,7 +323,7 @@ def test_cvt_golden(gpu, mode, dtype):
 		logits = model(x)
 		loss = ops.cross_entropy(logits.float(), y)
 	loss.backward()
-	tol, gtol = (2e-4, 1e-3) if dtype == torch.float32 else (3e-2, 8e-2)
+	tol, gtol = (1e-4, 1e-4) if dtype == torch.float32 else (3e-2, 5e-2)  # measured: 1.4e-6 / 3.3e-2 (three stages, BatchNorm in each embedding)
 	assert relerr(logits, g["logits"]) < tol
 	assert relerr(loss, g["loss"]) < tol
 	assert relerr(x.grad, g["grad_x"]) < gtol
@@ -611,7 +614,7 @@ def test_coatnet_harness_against_the_oracle(gpu, dtype, mode):
 	loss.backward()
 	fwd = lambda im, s: O.coatnet_fwd(im, s, cfg, training=(mode == "train"))
 	wl, wloss, wg, wgx = O.loss_and_grads(fwd, sd, x, y)
-	tol, gtol = (TOL[dtype], GTOL[dtype]) if dtype == torch.float32 else (3e-2, 8e-2)  # bf16: three BatchNorm stages deep, as for CvT
+	tol, gtol = (TOL[dtype], GTOL[dtype]) if dtype == torch.float32 else (3e-2, 6e-2)  # bf16: BatchNorm stages deep, as for CvT; measured 2.0e-6 / 4.2e-2
 	assert relerr(logits, wl) < tol and relerr(loss, wloss) < tol
 	assert relerr(xg.grad, wgx) < gtol * (5 if dtype == torch.float32 else 1)
 	gmax = max(float(v.abs().max()) for v in wg.values())

@@ -208,7 +208,7 @@ def test_vit_random_configs(gpu, case):
 def test_cvt_random_configs(gpu, case):
 	"""Whole CvT (conv embeddings with BatchNorm in training mode, conv-projection attention with strided keys, three
 	stages) for random widths / heads / depths / image sizes against the oracle's forward and its autograd gradients;
-	the bars are those of the golden CvT test (float32 2e-4 / 1e-3, bf16 3e-2 / 8e-2)."""
+	float32 at 1e-4 / 2e-4, bf16 at 3e-2 / 8e-2 (random configurations reach 4e-2)."""
 	import torch.nn as nn
 	from vit_amd import ops
 	from vit_amd.layers import RMSNorm
@@ -244,7 +244,7 @@ def test_cvt_random_configs(gpu, case):
 	y = torch.randint(0, c["out_d"], (B,))
 	ref_logits, ref_loss, ref_grads, ref_dx = O.loss_and_grads(lambda im, s: O.cvt_fwd(im, s, c, True), sd, x, y)
 	model = model.to(gpu).train()
-	for dtype, tol, gtol in ((torch.float32, 2e-4, 1e-3), (torch.bfloat16, 3e-2, 8e-2)):
+	for dtype, tol, gtol in ((torch.float32, 1e-4, 2e-4), (torch.bfloat16, 3e-2, 8e-2)):  # measured at most 4.0e-2 in bf16
 		model.load_state_dict(sd)  # BatchNorm running statistics move with every training forward
 		model.zero_grad()
 		xi = x.to(gpu).requires_grad_(True)
@@ -255,11 +255,7 @@ def test_cvt_random_configs(gpu, case):
 		assert relerr(logits, ref_logits) < tol, (c, dtype)
 		assert relerr(xi.grad, ref_dx) < gtol, (c, dtype)
 		for k, p in model.named_parameters():
-			# bias gradients are sums over all tokens of bf16-rounded gradients that largely cancel (|sum| << sum of |terms|):
-			# their rounding noise is a larger fraction of their own maximum than for weights (checked: the kernels' sums are
-			# exact to 1e-7 for the bf16 values they are given; float32 holds 1e-3 on the same cases)
-			bound = gtol if not (dtype == torch.bfloat16 and k.endswith("bias")) else 0.2
-			assert relerr(p.grad, ref_grads[k]) < bound, (c, k, dtype)
+			assert relerr(p.grad, ref_grads[k]) < gtol, (c, k, dtype)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
@@ -404,7 +400,7 @@ def test_conv_embedding_many_rows(gpu, dtype, ci, co, k, s, p, hw, B):
 	x = x0.to(gpu).to(dtype).requires_grad_(True)
 	y = m(x)
 	y.backward(gy0.to(gpu).to(dtype))
-	tol, gtol = (2e-4, 1e-3) if dtype == torch.float32 else (2e-2, 6e-2)
+	tol, gtol = (1e-4, 2e-4) if dtype == torch.float32 else (2e-2, 4e-2)  # measured 4.2e-6 / 0.95e-2
 	assert relerr(y, y_ref.detach()) < tol
 	assert relerr(x.grad, xr.grad) < gtol
 	for kk, pp in m.named_parameters():
@@ -432,14 +428,13 @@ def test_conv_attention_many_rows(gpu, dtype, dim, heads, hw, stride, B):
 	x = x0.to(gpu).to(dtype).requires_grad_(True)
 	y = m(x, hw, hw)
 	y.backward(gy0.to(gpu).to(dtype))
-	tol, gtol = (1e-4, 1e-3) if dtype == torch.float32 else (2e-2, 6e-2)
+	tol, gtol = (1e-4, 2e-4) if dtype == torch.float32 else (2e-2, 4e-2)  # measured 3.7e-6 / 0.54e-2
 	assert relerr(y, y_ref.detach()) < tol
 	assert relerr(x.grad, xr.grad) < gtol
 	for kk, pp in m.named_parameters():
-		bound = gtol if not (dtype == torch.bfloat16 and kk.endswith("bias")) else 0.2  # token sums that largely cancel
 		if "k_proj.bias" in kk:
 			continue  # exactly zero in exact arithmetic (softmax is invariant to a shift of the scores): rounding noise only
-		assert relerr(pp.grad, leaf[kk].grad) < bound, kk
+		assert relerr(pp.grad, leaf[kk].grad) < gtol, kk
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
@@ -467,9 +462,8 @@ def test_mbconv_many_rows(gpu, dtype, ci, co, stride, expand, hw, B):
 	x = x0.to(gpu).to(dtype).requires_grad_(True)
 	y = m(x)
 	y.backward(gy0.to(gpu).to(dtype))
-	tol, gtol = (2e-4, 2e-3) if dtype == torch.float32 else (3e-2, 8e-2)
+	tol, gtol = (1e-4, 2e-4) if dtype == torch.float32 else (3e-2, 5e-2)  # measured 4.8e-6 / 2.4e-2
 	assert relerr(y, y_ref.detach()) < tol
 	assert relerr(x.grad, xr.grad) < gtol
 	for kk, pp in m.named_parameters():
-		bound = gtol if not (dtype == torch.bfloat16 and kk.endswith("bias")) else 0.2
-		assert relerr(pp.grad, leaf[kk].grad) < bound, kk
+		assert relerr(pp.grad, leaf[kk].grad) < gtol, kk

@@ -111,6 +111,54 @@ def teacher_fixture(args):
 	save(args.out, "resnet20_teacher", arrays, {"kind": "teacher", "depth": 20, "num_classes": 10, "weights": "checkpoints/resnet20_cifar10.pth"})
 
 
+def ref_bf16_errors(args):
+	"""What the reference itself loses when it runs in bfloat16: its ViT models (the four golden configurations) forward +
+	backward under torch.autocast("cpu", bfloat16) against its own float32 run on the same seeded input, per tensor, in the
+	error measure the parity tests use (max|a - b| / max|b|).  Written as JSON (numbers only) next to the goldens."""
+	from config import ViTConfig
+	from layers.attention import MHA
+	from layers.norm import RMSNorm
+	from models.vit import ViT
+	ce = nn.CrossEntropyLoss()
+	out = {}
+	for name in ("vit_ln_gelu", "vit_p4_n65", "vit_rms_swiglu_ls", "vit_p16_geglu"):
+		z = np.load(os.path.join(args.out, name + ".npz"), allow_pickle=False)
+		c = json.loads(bytes(z["meta"]).decode())["config"]
+
+		class Cfg(ViTConfig):
+			pass
+		for k, v in c.items():
+			if k not in ("norm", "batch"):
+				setattr(Cfg, k, tuple(v) if isinstance(v, list) else v)
+		Cfg.attention = MHA
+		Cfg.norm = nn.LayerNorm if c["norm"] == "layernorm" else RMSNorm
+		Cfg.dropout = 0.0
+		Cfg.use_qk_norm = False
+		model = ViT(Cfg())
+		model.load_state_dict({k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd/")}, strict=True)
+		x = torch.from_numpy(z["x"]).requires_grad_(True)
+		y = torch.from_numpy(z["y"])
+		model.zero_grad()
+		with torch.autocast("cpu", dtype=torch.bfloat16):
+			o = model(x)
+			logits = o[0] if isinstance(o, tuple) else o
+			loss = ce(logits.float(), y)
+		loss.backward()
+		rel = lambda a, b: float(((a.double() - b.double()).abs().max() / b.double().abs().max().clamp_min(1e-30)))
+		rec = {"logits": rel(logits, torch.from_numpy(z["logits"])), "grad_x": rel(x.grad, torch.from_numpy(z["grad_x"]))}
+		worst = ("", 0.0)
+		for k, p_ in model.named_parameters():
+			e = rel(p_.grad, torch.from_numpy(z["grad/" + k]))
+			rec["grad/" + k] = e
+			if e > worst[1]:
+				worst = (k, e)
+		rec["worst_param_grad"] = {"name": worst[0], "err": worst[1]}
+		out[name] = rec
+		print(name, "logits", f"{rec['logits']:.3g}", "worst grad", worst)
+	with open(os.path.join(args.out, "ref_bf16_errors.json"), "w") as f:
+		json.dump({"what": "reference modules, torch.autocast('cpu', bfloat16) vs their float32 run; max|a-b|/max|b| per tensor", "torch": torch.__version__, "errors": out}, f, indent=1, sort_keys=True)
+
+
 def dyt_fixture(args):
 	"""DyT (layers/norm.py:35-45 there) alone, and a ViTBlock built with config.norm = DyT (layers/vit.py:9-60): inputs,
 	parameters, outputs, every gradient, float32 on the CPU."""
@@ -158,7 +206,7 @@ def main():
 	ap = argparse.ArgumentParser()
 	ap.add_argument("--reference", default="/root/reference")
 	ap.add_argument("--out", default="tests/golden")
-	ap.add_argument("--only", default="", help="generate only this fixture (mbconv, teacher, dyt)")
+	ap.add_argument("--only", default="", help="generate only this fixture (mbconv, teacher, dyt, ref_bf16)")
 	args = ap.parse_args()
 	sys.path.insert(0, args.reference)
 	os.makedirs(args.out, exist_ok=True)
@@ -172,6 +220,9 @@ def main():
 		return
 	if args.only == "dyt":
 		dyt_fixture(args)
+		return
+	if args.only == "ref_bf16":
+		ref_bf16_errors(args)
 		return
 	from config import ViTConfig, CvTConfig
 	from layers.attention import MHA, ConvAttention
