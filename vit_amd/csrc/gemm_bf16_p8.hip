@@ -10,25 +10,28 @@
 // wave columns (LDS row wc * 32 + j <-> tile column wc * 64 + h' * 32 + j), so that one quadrant of every wave needs exactly
 // one A and one B half-tile.  LDS holds two K steps (2 x 4 half-tiles, 128 KiB) + 8 x 4 KiB of epilogue images.
 //
-// A K step runs as four phases, one quadrant each (16 MFMAs per wave):
-//     phase 1: read B_0, A_0   quadrant (0,0)        phase 3: read A_1   quadrant (1,1)
-//     phase 2: read B_1        quadrant (0,1)        phase 4: read B_0   quadrant (1,0)
-// Every phase also issues the LDS-DMA (global_load_lds_dwordx4, two requests per lane) of ONE half-tile: the one whose
-// last fragment read was retired in the phase before, refilled for the K step that will use that buffer next
-// (phase 1: B_0 of step u+1, phases 2-4: A_0, B_1, A_1 of step u+2).  The only wait on that stream is one counted
-// s_waitcnt vmcnt(6) per K step (phase 4): it leaves the three newest half-tiles in flight, so the memory pipeline never
-// drains, and operand requests run 1.75 K steps ahead of their use, across tile boundaries too.
+// A K step runs as two phases of 32 MFMAs per wave:
+//     phase A: read B_0, B_1, A_0   row half 0 (quadrants (0,0), (0,1))     DMA: A_1 of K step u+1
+//     phase B: read A_1             row half 1 (quadrants (1,0), (1,1))     DMA: A_0, B_0, B_1 of K step u+2
+// Each phase refills (LDS-DMA, global_load_lds_dwordx4, two requests per lane and half-tile) the half-tiles whose last
+// fragment read was retired in the phase before, for the K step that will use that buffer next.  The only waits on that
+// stream are counted: s_waitcnt vmcnt(6) in phase A (all but the six newest requests -- A_0, B_0, B_1 of the next step --
+// have landed, so this step's A_1 is in LDS) and vmcnt(2) in phase B (all but A_1 of the next step have landed, so the next
+// step's A_0, B_0, B_1 are in LDS).  The memory pipeline never drains, and operand requests run 1.75 K steps ahead of
+// their use, across tile boundaries too (the first K step of a later tile adds the previous epilogue's operation count
+// to both waits, since those loads and stores are newer still and stay in flight).  (Four phases of 16 MFMAs were measured
+// first: no faster than one barrier per K step, every barrier pair costs about 64 cycles.)
 //
 // The two wave rows (waves 0-3 / 4-7, one wave of each per SIMD) run half a phase apart: each phase is
-// {fragment reads + DMA issue, barrier, 16 MFMAs, barrier}, and the second wave row starts one barrier late, so on every
+// {fragment reads + DMA issue, barrier, 32 MFMAs, barrier}, and the second wave row starts one barrier late, so on every
 // SIMD one wave is in its MFMA part while its partner is in its load part.
 //
 // Ordering rules the schedule obeys (an LDS-DMA is ordered for a reader only by the issuer's counted vmcnt followed by a
 // barrier the reader passes; an LDS read is retired only by the reading wave's lgkmcnt):
 //   - every wave retires a phase's fragment reads (lgkmcnt(0)) BEFORE that phase's first barrier, so a half-tile may be
 //     refilled by any wave from the next phase on;
-//   - the vmcnt(6) sits before phase 4's FIRST barrier, so that both wave rows have passed a barrier behind every wave's
-//     wait before the first read of the next K step (phase 1 of either wave row).
+//   - each counted vmcnt sits before its phase's FIRST barrier, so that both wave rows have passed a barrier behind every
+//     wave's wait before the first read of the half-tiles it covers.
 #include <cstdlib>
 #include <type_traits>
 
