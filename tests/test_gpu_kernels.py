@@ -370,7 +370,8 @@ def test_attention(gpu, dtype, B, h, Sq, Skv, dh):
 
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("B,h,Sq,Skv,dh,p", [(2, 12, 197, 197, 64, 0.3), (2, 3, 65, 65, 64, 0.1), (2, 2, 50, 13, 24, 0.3), (1, 2, 300, 300, 64, 0.5), (2, 2, 64, 16, 32, 0.3),
-	(70, 12, 65, 65, 64, 0.3), (67, 9, 40, 24, 64, 0.2)])  # the last two: more (batch, head) pairs than CUs, so a workgroup walks several pairs
+	(70, 12, 65, 65, 64, 0.3), (67, 9, 40, 24, 64, 0.2),  # these two: more (batch, head) pairs than CUs, so a workgroup walks several pairs
+	(2, 4, 784, 784, 12, 0.3), (2, 4, 196, 196, 24, 0.2), (1, 2, 300, 77, 40, 0.3), (1, 2, 520, 520, 64, 0.1), (1, 3, 129, 64, 8, 0.5)])  # key-blocked kernels
 def test_attention_dropout(gpu, dtype, B, h, Sq, Skv, dh, p):
 	"""Attention with dropout on the probabilities (the reference's training path, layers/attention.py:41,86): the
 	kernels' mask is regenerated on the CPU and handed to the oracle, so forward and all three gradients are compared

@@ -14,7 +14,8 @@
 //       O^T = V^T P^T with P^T taken from the accumulators of S^T as they stand (two 16-key tiles = one 32-deep k-step; the
 //       transposing read of V uses the matching key order)
 //   dK / dV (key on the lane):  S = Q K^T, dP = dO V^T, dV^T = dO^T P, dK^T = Q^T dS over all query blocks
-// The backward is two kernels so that no gradient needs a cross-workgroup sum.
+// The backward is two kernels so that no gradient needs a cross-workgroup sum.  Dropout on the probabilities (DROP): the
+// normaliser and lse are those of the undropped softmax; O, dP and the P that feeds dV carry the mask.
 #include "attention.h"
 
 namespace {
@@ -115,7 +116,9 @@ __device__ __forceinline__ void store4(bf16_t* row, int d0, int dh, const f32x4&
 }
 
 // ---- forward: one workgroup = 64 queries of one (batch, head), one wave = 16 of them -----------------------------
-template <int KS, int NDT>  // KS: 32-deep k-steps of Q K^T (head size padded to 32 KS); NDT: 16-column tiles of the output
+// KS: 32-deep k-steps of Q K^T (head size padded to 32 KS); NDT: 16-column tiles of the output; DROP: dropout on the
+// probabilities, the mask regenerated from a hash of (seed, batch * n_head + head, query, key pair) as in the other families
+template <int KS, int NDT, bool DROP>
 __global__ __launch_bounds__(256) void attn_flash_fwd_kernel(AttnArgs a) {
 	__shared__ __attribute__((aligned(16))) char smem[3 * IMG];
 	char *Qs = smem, *Ks = smem + IMG, *Vs = smem + 2 * IMG;
@@ -134,6 +137,7 @@ __global__ __launch_bounds__(256) void attn_flash_fwd_kernel(AttnArgs a) {
 #pragma unroll
 	for (int s = 0; s < KS; ++s) qf[s] = row_frag(Qs, 16 * wave, s, lane);
 	const float c = a.scale * LOG2E;
+	const uint32_t rk = DROP ? attn_row_key(attn_head_key(a, bh), q0 + 16 * wave + (lane & 15)) : 0u;
 	float m = -INFINITY, l = 0.f;  // running maximum (log2 units of the scaled scores) and normaliser of this lane's query
 	f32x4 o[NDT];
 #pragma unroll
@@ -178,8 +182,19 @@ __global__ __launch_bounds__(256) void attn_flash_fwd_kernel(AttnArgs a) {
 				st[t][r] = p;
 				ls += p;
 			}
-		l = l * alpha + group_sum(ls);
+		l = l * alpha + group_sum(ls);  // (the normaliser is that of the undropped probabilities)
 		m = mn;
+		if constexpr (DROP) {
+#pragma unroll
+			for (int t = 0; t < 4; ++t) {
+				const int kp = (k0 + 16 * t + 4 * g) >> 1;
+				const uint32_t b0 = attn_pair_bits(rk, kp), b1 = attn_pair_bits(rk, kp + 1);
+				st[t][0] *= attn_keep(b0, 0, a.drop_thr16, 1.f);
+				st[t][1] *= attn_keep(b0, 1, a.drop_thr16, 1.f);
+				st[t][2] *= attn_keep(b1, 0, a.drop_thr16, 1.f);
+				st[t][3] *= attn_keep(b1, 1, a.drop_thr16, 1.f);
+			}
+		}
 #pragma unroll
 		for (int dt = 0; dt < NDT; ++dt) o[dt] *= alpha;
 #pragma unroll
@@ -191,7 +206,7 @@ __global__ __launch_bounds__(256) void attn_flash_fwd_kernel(AttnArgs a) {
 	}
 	const int q = q0 + 16 * wave + (lane & 15);
 	if (q < a.Sq) {
-		const float inv = 1.f / l;
+		const float inv = (DROP ? a.drop_scale : 1.f) / l;
 		bf16_t* op = reinterpret_cast<bf16_t*>(a.out_w) + ((int64_t)b * a.Sq + q) * a.ldo + h * a.dh;
 #pragma unroll
 		for (int dt = 0; dt < NDT; ++dt) store4(op, 16 * dt + 4 * g, a.dh, o[dt], inv);
@@ -200,7 +215,7 @@ __global__ __launch_bounds__(256) void attn_flash_fwd_kernel(AttnArgs a) {
 }
 
 // ---- backward, dQ: one wave = 16 queries; also leaves lse (log2 units) and delta = rowsum(dO o O) in the scratch --------
-template <int KS, int NDT>
+template <int KS, int NDT, bool DROP>
 __global__ __launch_bounds__(256) void attn_flash_dq_kernel(AttnArgs a) {
 	__shared__ __attribute__((aligned(16))) char smem[4 * IMG];
 	char *Qs = smem, *Gs = smem + IMG, *Ks = smem + 2 * IMG, *Vs = smem + 3 * IMG;  // Ks doubles as the O image first
@@ -236,6 +251,7 @@ __global__ __launch_bounds__(256) void attn_flash_dq_kernel(AttnArgs a) {
 		a.bwd_scratch[((int64_t)n_bh + bh) * a.Sq + q] = delta;
 	}
 	const float c = a.scale * LOG2E;
+	const uint32_t rk = DROP ? attn_row_key(attn_head_key(a, bh), q) : 0u;
 	f32x4 dq[NDT];
 #pragma unroll
 	for (int dt = 0; dt < NDT; ++dt) dq[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -263,6 +279,14 @@ __global__ __launch_bounds__(256) void attn_flash_dq_kernel(AttnArgs a) {
 					s = mfma16(row_frag(Ks, 16 * t, ks, lane), qf[ks], s);
 					dp = mfma16(row_frag(Vs, 16 * t, ks, lane), gf[ks], dp);
 				}
+				if constexpr (DROP) {
+					const int kp = (k0 + 16 * t + 4 * g) >> 1;
+					const uint32_t b0 = attn_pair_bits(rk, kp), b1 = attn_pair_bits(rk, kp + 1);
+					dp[0] *= attn_keep(b0, 0, a.drop_thr16, a.drop_scale);
+					dp[1] *= attn_keep(b0, 1, a.drop_thr16, a.drop_scale);
+					dp[2] *= attn_keep(b1, 0, a.drop_thr16, a.drop_scale);
+					dp[3] *= attn_keep(b1, 1, a.drop_thr16, a.drop_scale);
+				}
 #pragma unroll
 				for (int r = 0; r < 4; ++r) {
 					const float p = __builtin_amdgcn_exp2f(s[r] * c - lse2);
@@ -282,12 +306,13 @@ __global__ __launch_bounds__(256) void attn_flash_dq_kernel(AttnArgs a) {
 }
 
 // ---- backward, dK / dV: one wave = 16 keys, summed over all query blocks ------------------------------------------------
-template <int KS, int NDT>
+template <int KS, int NDT, bool DROP>
 __global__ __launch_bounds__(256) void attn_flash_dkv_kernel(AttnArgs a) {
-	__shared__ __attribute__((aligned(16))) char smem[4 * IMG + 2 * 64 * 4];
+	__shared__ __attribute__((aligned(16))) char smem[4 * IMG + 3 * 64 * 4];
 	char *Ks = smem, *Vs = smem + IMG, *Qs = smem + 2 * IMG, *Gs = smem + 3 * IMG;
 	float* lse_s = reinterpret_cast<float*>(smem + 4 * IMG);
 	float* delta_s = lse_s + 64;
+	uint32_t* rk_s = reinterpret_cast<uint32_t*>(delta_s + 64);  // DROP: mask row keys of the block's 64 queries
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4;
 	const int bh = blockIdx.y, b = bh / a.n_head, h = bh - b * a.n_head;
 	const int n_bh = a.B * a.n_head;
@@ -328,6 +353,9 @@ __global__ __launch_bounds__(256) void attn_flash_dkv_kernel(AttnArgs a) {
 		commit_rows(Qs, qr, dh4);
 		commit_rows(Gs, gr, dh4);
 		if (threadIdx.x < 128) lse_s[threadIdx.x] = stat;  // delta_s follows lse_s
+		if constexpr (DROP) {
+			if (threadIdx.x >= 192) rk_s[threadIdx.x - 192] = attn_row_key(attn_head_key(a, bh), q0 + (int)threadIdx.x - 192);
+		}
 		__syncthreads();
 		if (q0 + 64 < a.Sq) {
 			fetch_rows(qr, qb, a.ldq, q0 + 64, a.Sq, dh4);
@@ -348,11 +376,20 @@ __global__ __launch_bounds__(256) void attn_flash_dkv_kernel(AttnArgs a) {
 				}
 				const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_s + 16 * t + 4 * g);
 				const f32x4 d4 = *reinterpret_cast<const f32x4*>(delta_s + 16 * t + 4 * g);
+				float keep[4] = {1.f, 1.f, 1.f, 1.f};
+				if constexpr (DROP) {
+					const int key = k0 + 16 * wave + (lane & 15);
+					const uint4 rk4 = *reinterpret_cast<const uint4*>(rk_s + 16 * t + 4 * g);
+					keep[0] = attn_keep(attn_pair_bits(rk4.x, key >> 1), key, a.drop_thr16, a.drop_scale);
+					keep[1] = attn_keep(attn_pair_bits(rk4.y, key >> 1), key, a.drop_thr16, a.drop_scale);
+					keep[2] = attn_keep(attn_pair_bits(rk4.z, key >> 1), key, a.drop_thr16, a.drop_scale);
+					keep[3] = attn_keep(attn_pair_bits(rk4.w, key >> 1), key, a.drop_thr16, a.drop_scale);
+				}
 #pragma unroll
 				for (int r = 0; r < 4; ++r) {
 					const float p = __builtin_amdgcn_exp2f(s[r] * c - l4[r]);
-					pr[hf][r] = p;
-					ds[hf][r] = p * (dp[r] - d4[r]) * a.scale;
+					pr[hf][r] = DROP ? p * keep[r] : p;
+					ds[hf][r] = p * ((DROP ? dp[r] * keep[r] : dp[r]) - d4[r]) * a.scale;
 				}
 			}
 			const bf16x8 pf = pack8(pr[0], pr[1]), dsf = pack8(ds[0], ds[1]);
@@ -375,19 +412,24 @@ __global__ __launch_bounds__(256) void attn_flash_dkv_kernel(AttnArgs a) {
 	}
 }
 
-template <int KS, int NDT>
-int run(const AttnArgs& a, bool bwd, hipStream_t st) {
+template <int KS, int NDT, bool DROP>
+int run_d(const AttnArgs& a, bool bwd, hipStream_t st) {
 	const unsigned n_bh = (unsigned)(a.B * a.n_head);
 	if (!bwd) {
-		hipLaunchKernelGGL((attn_flash_fwd_kernel<KS, NDT>), dim3((unsigned)vitk_cdiv(a.Sq, 64), n_bh), dim3(256), 0, st, a);
+		hipLaunchKernelGGL((attn_flash_fwd_kernel<KS, NDT, DROP>), dim3((unsigned)vitk_cdiv(a.Sq, 64), n_bh), dim3(256), 0, st, a);
 		VITK_CHECK_LAUNCH();
 		return VITK_OK;
 	}
-	hipLaunchKernelGGL((attn_flash_dq_kernel<KS, NDT>), dim3((unsigned)vitk_cdiv(a.Sq, 64), n_bh), dim3(256), 0, st, a);
+	hipLaunchKernelGGL((attn_flash_dq_kernel<KS, NDT, DROP>), dim3((unsigned)vitk_cdiv(a.Sq, 64), n_bh), dim3(256), 0, st, a);
 	VITK_CHECK_LAUNCH();
-	hipLaunchKernelGGL((attn_flash_dkv_kernel<KS, NDT>), dim3((unsigned)vitk_cdiv(a.Skv, 64), n_bh), dim3(256), 0, st, a);
+	hipLaunchKernelGGL((attn_flash_dkv_kernel<KS, NDT, DROP>), dim3((unsigned)vitk_cdiv(a.Skv, 64), n_bh), dim3(256), 0, st, a);
 	VITK_CHECK_LAUNCH();
 	return VITK_OK;
+}
+
+template <int KS, int NDT>
+int run(const AttnArgs& a, bool bwd, hipStream_t st) {
+	return a.drop_thr16 != 0 ? run_d<KS, NDT, true>(a, bwd, st) : run_d<KS, NDT, false>(a, bwd, st);
 }
 
 bool al8(const void* p) { return p == nullptr || vitk_aligned(p, 8); }
@@ -396,7 +438,6 @@ bool al8(const void* p) { return p == nullptr || vitk_aligned(p, 8); }
 
 bool vitk_attention_flash_ok(const AttnArgs& a, int dtype) {
 	if (dtype != VITK_BF16 || a.dh < 4 || a.dh > 64 || a.dh % 4 != 0) return false;
-	if (a.drop_thr16 != 0) return false;  // attention-probability dropout stays on the other kernels
 	if ((a.ldq | a.ldk | a.ldv | a.ldo) % 4 != 0) return false;
 	if (a.dq != nullptr && ((a.lddq | a.lddk | a.lddv) % 4 != 0)) return false;
 	if ((int64_t)a.B * a.n_head > 65535) return false;  // grid.y
