@@ -444,6 +444,12 @@ int vitk_gemm_bf16(const vitk_gemm_desc& d, hipStream_t st, bool* colsum_done) {
 	*colsum_done = false;
 	// Problems whose 256x256 tiles leave the last round of the persistent kernel mostly empty (N = 768 at 50,432 rows: 591
 	// tiles = 2.3 rounds of 256) run on the 128x256-tile kernel, which balances the tail at half the granularity.
+	// Few rows (CvT's last stage: 4096 tokens x 384 ... 1536 features): 256 x 256 tiles would occupy a fraction of the CUs with
+	// one workgroup each and nothing to split; four times as many 128 x 128 tiles fill the chip better.  (Weight gradients
+	// split K instead and stay on the large tiles.)
+	static const bool small_rule = getenv("VITK_NO_SMALL_TILE_RULE") == nullptr;  // A-B switch
+	const int64_t t256n = vitk_cdiv(d.M, 256) * vitk_cdiv(d.N, 256);
+	const bool starved = small_rule && d.out_dtype == VITK_BF16 && t256n < 128;  // (thresholds 64 ... 256 measured the same on the CvT step: 7.9 -> 6.6 ms)
 	static const bool p8 = getenv("VITK_NO_P8") == nullptr;  // A-B switch
 	if (p8 && big_tiles && d.a_colsum == nullptr && vitk_gemm_bf16_p8_ok(d) && d.M * d.N >= 32ll * 256 * 256) {
 		// (Cutting a launch whose last round is mostly empty -- N = 768: 591 tiles = 2.31 rounds -- into whole rounds here plus
@@ -456,7 +462,7 @@ int vitk_gemm_bf16(const vitk_gemm_desc& d, hipStream_t st, bool* colsum_done) {
 		const int64_t r256 = vitk_cdiv(t256, 256), r128 = vitk_cdiv(t128n, 256);  // rounds in units of a CU's tile time / half of it
 		if (t256 > 256 && r128 * 10 < r256 * 2 * 9) return vitk_gemm_bf16_t128(d, st);
 	}
-	if (big_tiles && vitk_gemm_bf16_256_ok(d)) {
+	if (big_tiles && !starved && vitk_gemm_bf16_256_ok(d)) {
 		const int rc = vitk_gemm_bf16_256(d, st, colsum_done);
 		if (rc != VITK_ERR_UNSUPPORTED) return rc;
 	}
