@@ -817,13 +817,25 @@ class PatchEmbedFn(torch.autograd.Function):
 		d, K = w.shape
 		dx = cast(dx, dt)
 		dtc = L.dtype_code(dt)
-		dpos = torch.empty((P2 + lead, d), dtype=torch.float32, device=dx.device)
-		L.check(lib.vitk_batch_sum(L.ptr(dx), L.ptr(dpos), Bn, P2 + lead, d, 0, dtc, L.stream()))
+		sk = _Sinks(w=w, b=b, cls=class_token, pos=pos_embed, dist=dist_token)
+		S = P2 + lead
+		# d pos_embed = sum over the batch of dx; d class_token (d dist_token) = the same sum of token row 0 (1) alone, read
+		# through the row stride.  Each goes straight into its gradient sink where there is one.
+		dpos = sk.buf("pos") if sk.buf("pos") is not None else torch.empty((S, d), dtype=torch.float32, device=dx.device)
+		L.check(lib.vitk_batch_sum(L.ptr(dx), L.ptr(dpos), Bn, S, d, int(sk.buf("pos") is not None), dtc, L.stream()))
+
+		def lead_row_grad(name, param, r):
+			buf = sk.buf(name)
+			out = buf if buf is not None else torch.empty(d, dtype=torch.float32, device=dx.device)
+			L.check(lib.vitk_colsum(dx.data_ptr() + r * d * dx.element_size(), L.ptr(out), Bn, d, S * d, int(buf is not None), dtc, L.stream()))
+			return sk.ret(name, out.reshape(param.shape))
+		dcls = lead_row_grad("cls", class_token, 0)
+		ddist = None if dist_token is None else lead_row_grad("dist", dist_token, 1)
 		dtok = torch.empty((Bn * P2, d), dtype=dt, device=dx.device)
-		L.check(lib.vitk_drop_lead_rows(L.ptr(dx), L.ptr(dtok), Bn, P2 + lead, d, lead, dtc, L.stream()))
+		L.check(lib.vitk_drop_lead_rows(L.ptr(dx), L.ptr(dtok), Bn, S, d, lead, dtc, L.stream()))
 		patches = torch.empty((Bn * P2, K), dtype=dt, device=dx.device)
 		L.check(lib.vitk_patchify(L.ptr(img), L.ptr(patches), Bn, C, H, n_patch, dtc, L.stream()))
-		dw, db = linear_wgrad(dtok, patches, bias_grad=True)
+		dw, db = linear_wgrad(dtok, patches, bias_grad=True, dw_out=sk.buf("w"), db_out=sk.buf("b"))
 		dimg = None
 		if ctx.needs_input_grad[0]:
 			dpatch = linear_dgrad(dtok, weight_as(w, dt))
@@ -831,10 +843,7 @@ class PatchEmbedFn(torch.autograd.Function):
 			L.check(lib.vitk_unpatchify(L.ptr(dpatch), L.ptr(dimg), Bn, C, H, n_patch, dtc, L.stream()))
 			if dimg.dtype != idtype:
 				dimg = cast(dimg, idtype)
-		dcls = dpos[0:1].clone()
-		ddist = None if dist_token is None else grad_as(dpos[1:2].clone().reshape(dist_token.shape), dist_token)
-		return (dimg, grad_as(dw, w), grad_as(db, b), grad_as(dcls.reshape(class_token.shape), class_token), grad_as(dpos.reshape(pos_embed.shape), pos_embed), None,
-			ddist)
+		return (dimg, sk.ret("w", dw), sk.ret("b", db), dcls, sk.ret("pos", dpos.reshape(pos_embed.shape)), None, ddist)
 
 
 class DualHeadFn(torch.autograd.Function):
@@ -867,10 +876,11 @@ class DualHeadFn(torch.autograd.Function):
 		grads = []
 		for r, dy, w, b in ((0, dy0, w_cls, b_cls), (1, dy1, w_dist, b_dist)):
 			dyc = cast(dy, dt)
-			dw, db = linear_wgrad(dyc, rows[r::S], bias_grad=b is not None)
+			sk = _Sinks(w=w, b=b)
+			dw, db = linear_wgrad(dyc, rows[r::S], bias_grad=True, dw_out=sk.buf("w"), db_out=sk.buf("b"))
 			if dx is not None:
 				linear_dgrad(dyc, weight_as(w, dt), out=dx.reshape(Bn * S, d)[r::S])
-			grads += [grad_as(dw, w), grad_as(db, b)]
+			grads += [sk.ret("w", dw), sk.ret("b", db)]
 		if dx is not None and dx.dtype != xdtype:
 			dx = cast(dx, xdtype)
 		return (dx, *grads)
@@ -898,14 +908,15 @@ class ClsHeadFn(torch.autograd.Function):
 		Bn, S, d = xc.shape
 		dy2 = cast(dy, dt)
 		rows0 = xc.reshape(Bn * S, d)[::S]
-		dw, db = linear_wgrad(dy2, rows0, bias_grad=True)
+		sk = _Sinks(w=w, b=b)
+		dw, db = linear_wgrad(dy2, rows0, bias_grad=True, dw_out=sk.buf("w"), db_out=sk.buf("b"))
 		dx = None
 		if ctx.needs_input_grad[0]:
 			dx = torch.zeros((Bn, S, d), dtype=dt, device=dy.device)
 			linear_dgrad(dy2, weight_as(w, dt), out=dx.reshape(Bn * S, d)[::S])
 			if dx.dtype != xdtype:
 				dx = cast(dx, xdtype)
-		return dx, grad_as(dw, w), grad_as(db, b)
+		return dx, sk.ret("w", dw), sk.ret("b", db)
 
 
 class CeKdLossFn(torch.autograd.Function):
