@@ -146,16 +146,21 @@ const char* vitk_gemm_last_kernel(void);
  * residual stream, may alias x) and normalises s.
  * Backward: dx = d(loss)/d(x) of y = norm(x); if `dres` is non-null it is added to dx
  * (gradient flowing around the norm on the residual stream).  dgamma / dbeta are float32
- * [d] and are ACCUMULATED into (the caller zeroes them), through per-block partial sums.
+ * [d] and are ACCUMULATED into (the caller zeroes them).  `workspace` (optional device scratch, 16-byte
+ * aligned, at least 2048 * d bytes; the call allocates nothing itself): the per-workgroup column sums go
+ * through it and a second small launch adds them up in a fixed order; without it they are added with float
+ * atomics, whose same-address queue costs about 10 us per call.
  */
 int vitk_layernorm_fwd(const void* x, const void* res, const float* gamma, const float* beta,
 	void* y, void* sum_out, float* mean, float* rstd, int64_t rows, int64_t d, float eps, int dtype, void* stream);
 int vitk_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
-	const void* dres, void* dx, float* dgamma, float* dbeta, int64_t rows, int64_t d, int dtype, void* stream);
+	const void* dres, void* dx, float* dgamma, float* dbeta, int64_t rows, int64_t d, int dtype, void* workspace,
+	int64_t workspace_bytes, void* stream);
 int vitk_rmsnorm_fwd(const void* x, const void* res, const float* weight, void* y, void* sum_out, float* rstd,
 	int64_t rows, int64_t d, float eps, int unit_offset, int dtype, void* stream);
 int vitk_rmsnorm_bwd(const void* dy, const void* x, const float* weight, const float* rstd, const void* dres,
-	void* dx, float* dweight, int64_t rows, int64_t d, int unit_offset, int dtype, void* stream);
+	void* dx, float* dweight, int64_t rows, int64_t d, int unit_offset, int dtype, void* workspace, int64_t workspace_bytes,
+	void* stream);
 /* DyT, the dynamic-tanh stand-in for a norm (layers/norm.py:35-45): y = gamma * tanh(alpha[0] * x) + beta over the last
  * dimension d (<= 4096 with 16-byte accessible rows and d % 4 == 0, else <= 1024).  Backward: dx, and dalpha (1 float),
  * dgamma, dbeta ([d] floats) ACCUMULATED into (the caller zeroes them). */

@@ -332,6 +332,11 @@ def test_norms(gpu, dtype, kind, rows, d):
 		dx_ref, dw_ref = O.rmsnorm_bwd(dyr, s_ref, w.double(), r_ref, True)
 	assert relerr(dx, dx_ref + dresr) < TOL[dtype]
 	assert relerr(dw, dw_ref) < 1e-4
+	# without the scratch buffer the column sums are added with float atomics: same results
+	dx2, dw2, db2 = ops.norm_bwd(dy, s, w.to(gpu), mean, rstd, kind, True, dres=dres, workspace=False)
+	assert torch.equal(dx2, dx) and relerr(dw2, dw_ref) < 1e-4
+	if kind == "layernorm":
+		assert relerr(db2, db_ref) < 1e-4
 
 
 @pytest.mark.parametrize("dtype", DTYPES)

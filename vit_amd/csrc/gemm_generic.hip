@@ -22,35 +22,49 @@ __device__ __forceinline__ float load_b(const GemmDev& g, int64_t n, int k) {
 	return to_f32<TIN>(g.b_layout == VITK_K_MAJOR ? B[n * g.ldb + k] : B[(int64_t)k * g.ldb + n]);
 }
 
+// k_per_split (a multiple of BK) > 0: blockIdx.z owns the K range [z * k_per_split, (z + 1) * k_per_split) and adds its
+// partial sums into C with float atomics (float32 output without epilogue only; C holds the value to add to).
 template <typename TIN, typename TOUT>
-__global__ __launch_bounds__(256) void gemm_generic_kernel(GemmDev g) {
+__global__ __launch_bounds__(256) void gemm_generic_kernel(GemmDev g, int k_per_split) {
 	__shared__ float As[BK * LDS_LD];
 	__shared__ float Bs[BK * LDS_LD];
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	const int64_t m0 = (int64_t)blockIdx.y * BM, n0 = (int64_t)blockIdx.x * BN;
 	const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
 	f32x16 acc = {};
-	const int K = (int)g.K;
+	const int k_begin = k_per_split > 0 ? (int)blockIdx.z * k_per_split : 0;
+	const int K = k_per_split > 0 ? min((int)g.K, k_begin + k_per_split) : (int)g.K;
 	// thread -> element of the 64 x 32 staging tile: consecutive threads follow the contiguous index
 	const bool a_kmajor = (g.a_layout == VITK_K_MAJOR) || g.patch_grid > 0;
 	const bool b_kmajor = (g.b_layout == VITK_K_MAJOR);
-	for (int k0 = 0; k0 < K; k0 += BK) {
+	// the operands of the next K step are in flight (in registers) while the matrix unit works on this one
+	float ra[8], rb[8];
+	auto fetch = [&](int k0) {
 #pragma unroll
 		for (int i = 0; i < 8; ++i) {
 			int mm, kk;
 			if (a_kmajor) { kk = tid & 31; mm = (tid >> 5) + 8 * i; } else { mm = tid & 63; kk = (tid >> 6) + 4 * i; }
 			const int64_t m = m0 + mm;
-			float v = 0.f;
-			if (m < g.M && k0 + kk < K) v = load_a<TIN>(g, m, k0 + kk);
-			As[kk * LDS_LD + mm] = v;
+			ra[i] = (m < g.M && k0 + kk < K) ? load_a<TIN>(g, m, k0 + kk) : 0.f;
 			int nn, kb;
 			if (b_kmajor) { kb = tid & 31; nn = (tid >> 5) + 8 * i; } else { nn = tid & 63; kb = (tid >> 6) + 4 * i; }
 			const int64_t n = n0 + nn;
-			float w = 0.f;
-			if (n < g.N && k0 + kb < K) w = load_b<TIN>(g, n, k0 + kb);
-			Bs[kb * LDS_LD + nn] = w;
+			rb[i] = (n < g.N && k0 + kb < K) ? load_b<TIN>(g, n, k0 + kb) : 0.f;
+		}
+	};
+	fetch(k_begin);
+	for (int k0 = k_begin; k0 < K; k0 += BK) {
+#pragma unroll
+		for (int i = 0; i < 8; ++i) {
+			int mm, kk;
+			if (a_kmajor) { kk = tid & 31; mm = (tid >> 5) + 8 * i; } else { mm = tid & 63; kk = (tid >> 6) + 4 * i; }
+			As[kk * LDS_LD + mm] = ra[i];
+			int nn, kb;
+			if (b_kmajor) { kb = tid & 31; nn = (tid >> 5) + 8 * i; } else { nn = tid & 63; kb = (tid >> 6) + 4 * i; }
+			Bs[kb * LDS_LD + nn] = rb[i];
 		}
 		__syncthreads();
+		if (k0 + BK < K) fetch(k0 + BK);
 #pragma unroll
 		for (int ks = 0; ks < BK; ks += 2) {
 			const float a = As[(ks + (lane >> 5)) * LDS_LD + wm + (lane & 31)];
@@ -65,7 +79,14 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(GemmDev g) {
 #pragma unroll
 		for (int r = 0; r < 16; ++r) {
 			const int64_t m = m0 + wm + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-			if (m < g.M) epi_store1<TIN, TOUT>(g, m, n, acc[r]);
+			if (m >= g.M) continue;
+			if constexpr (sizeof(TOUT) == 4) {
+				if (k_per_split > 0) {
+					atomicAdd(reinterpret_cast<float*>(g.C) + m * g.ldc + n, acc[r]);
+					continue;
+				}
+			}
+			epi_store1<TIN, TOUT>(g, m, n, acc[r]);
 		}
 	}
 }
@@ -77,14 +98,30 @@ thread_local const char* vitk_last_gemm_kernel = "";
 int vitk_gemm_generic(const vitk_gemm_desc& d, hipStream_t st) {
 	vitk_last_gemm_kernel = "gemm_generic_kernel";
 	GemmDev g = make_gemm_dev(d);
-	dim3 grid((unsigned)vitk_cdiv(d.N, BN), (unsigned)vitk_cdiv(d.M, BM));
+	const int64_t tiles = vitk_cdiv(d.N, BN) * vitk_cdiv(d.M, BM), ksteps = vitk_cdiv(d.K, BK);
 	VITK_REQUIRE(vitk_cdiv(d.M, BM) <= 65535, VITK_ERR_SHAPE);
+	// Few output tiles over a long K (the weight gradient of a 10-class head: one tile, K = the batch): the K loop of one
+	// workgroup is a chain of load -> LDS -> matrix unit steps, so the K range is cut over workgroups that add their
+	// partial sums with float atomics.  bf16 operands only: the float32 path keeps its fixed summation order.
+	int splits = 1, k_per_split = 0;
+	if (d.in_dtype == VITK_BF16 && d.out_dtype == VITK_F32 && d.epilogue == VITK_EPI_NONE && d.bias == nullptr && d.tokens_per_image == 0 &&
+		tiles <= 64 && ksteps >= 4) {
+		const int64_t steps_per = std::max<int64_t>(2, vitk_cdiv(ksteps, std::max<int64_t>(1, 256 / tiles)));
+		k_per_split = (int)(steps_per * BK);
+		splits = (int)vitk_cdiv(ksteps, steps_per);
+		if (splits <= 1) { splits = 1; k_per_split = 0; }
+	}
+	if (splits > 1 && !d.accumulate) {
+		hipError_t e = hipMemset2DAsync(d.C, (size_t)d.ldc * sizeof(float), 0, (size_t)d.N * sizeof(float), (size_t)d.M, st);
+		if (e != hipSuccess) return VITK_ERR_HIP - (int)e;
+	}
+	dim3 grid((unsigned)vitk_cdiv(d.N, BN), (unsigned)vitk_cdiv(d.M, BM), (unsigned)splits);
 	if (d.in_dtype == VITK_F32 && d.out_dtype == VITK_F32)
-		hipLaunchKernelGGL((gemm_generic_kernel<float, float>), grid, dim3(256), 0, st, g);
+		hipLaunchKernelGGL((gemm_generic_kernel<float, float>), grid, dim3(256), 0, st, g, k_per_split);
 	else if (d.in_dtype == VITK_BF16 && d.out_dtype == VITK_BF16)
-		hipLaunchKernelGGL((gemm_generic_kernel<bf16_t, bf16_t>), grid, dim3(256), 0, st, g);
+		hipLaunchKernelGGL((gemm_generic_kernel<bf16_t, bf16_t>), grid, dim3(256), 0, st, g, k_per_split);
 	else if (d.in_dtype == VITK_BF16 && d.out_dtype == VITK_F32)
-		hipLaunchKernelGGL((gemm_generic_kernel<bf16_t, float>), grid, dim3(256), 0, st, g);
+		hipLaunchKernelGGL((gemm_generic_kernel<bf16_t, float>), grid, dim3(256), 0, st, g, k_per_split);
 	else
 		return VITK_ERR_DTYPE;
 	VITK_CHECK_LAUNCH();

@@ -1,29 +1,42 @@
 // LayerNorm / RMSNorm forward and backward with optional fused residual add.
 //
-// Bandwidth-bound: one 64-lane wavefront owns one row, keeps it in registers (ITERS 16-byte
-// chunks per lane), and reduces with cross-lane shuffles.  Algorithmic HBM bytes per row:
-// forward 2*d*e (+ 2*d*e with the fused residual add), backward 3*d*e (+ d*e with dres).
+// Bandwidth-bound: a group of LPR lanes (64 = a whole wavefront; 8, 16 or 32 for rows of at most 1 KB, so that a
+// wavefront works on 64 / LPR rows at once and every load instruction still covers whole 128-byte lines) owns one row,
+// keeps it in registers (ITERS chunks of VEC elements per lane), and reduces with cross-lane shuffles.  Algorithmic
+// HBM bytes per row: forward 2*d*e (+ 2*d*e with the fused residual add), backward 3*d*e (+ d*e with dres).
 #include "vitk_common.h"
 
 namespace {
 
-template <typename T, int VEC, int ITERS, bool RMS>
+// sum over the LPR consecutive lanes of a row group
+template <int LPR>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+	for (int o = LPR / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+	return v;
+}
+
+template <typename T, int VEC, int ITERS, bool RMS, int LPR>
 __global__ __launch_bounds__(256) void norm_fwd_kernel(const T* __restrict__ x, const T* __restrict__ res,
 	const float* __restrict__ gamma, const float* __restrict__ beta, T* __restrict__ y, T* sum_out,
 	float* __restrict__ mean_out, float* __restrict__ rstd_out, int64_t rows, int d, float eps, float offset) {
+	constexpr int RPW = 64 / LPR;  // rows per wavefront
 	const int lane = threadIdx.x & 63;
 	const int wave = threadIdx.x >> 6;
-	const int64_t nwaves = (int64_t)gridDim.x * 4;
+	const int l = lane % LPR, sub = lane / LPR;
+	const int64_t step = (int64_t)gridDim.x * 4 * RPW;
 	const int nchunk = d / VEC;
 	const float inv_d = 1.0f / (float)d;
-	for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += nwaves) {
+	for (int64_t base = ((int64_t)blockIdx.x * 4 + wave) * RPW; base < rows; base += step) {
+		const int64_t row = base + sub;
+		const bool live = row < rows;
 		const T* xr = x + row * d;
 		float v[ITERS][VEC];
 		float s = 0.f;
 #pragma unroll
 		for (int it = 0; it < ITERS; ++it) {
-			const int c = lane + it * 64;
-			if (c < nchunk) {
+			const int c = l + it * LPR;
+			if (live && c < nchunk) {
 				load_vec<T, VEC>(xr + c * VEC, v[it]);
 				if (res != nullptr) {
 					float r[VEC];
@@ -39,7 +52,7 @@ __global__ __launch_bounds__(256) void norm_fwd_kernel(const T* __restrict__ x, 
 				for (int j = 0; j < VEC; ++j) v[it][j] = 0.f;
 			}
 		}
-		s = wave_sum(s);
+		s = group_sum<LPR>(s);
 		float mu = 0.f, rstd;
 		if (RMS) {
 			rstd = rsqrtf(s * inv_d + eps);
@@ -48,7 +61,7 @@ __global__ __launch_bounds__(256) void norm_fwd_kernel(const T* __restrict__ x, 
 			float q = 0.f;
 #pragma unroll
 			for (int it = 0; it < ITERS; ++it) {
-				if (lane + it * 64 < nchunk) {
+				if (l + it * LPR < nchunk) {
 #pragma unroll
 					for (int j = 0; j < VEC; ++j) {
 						const float t = v[it][j] - mu;
@@ -56,17 +69,17 @@ __global__ __launch_bounds__(256) void norm_fwd_kernel(const T* __restrict__ x, 
 					}
 				}
 			}
-			q = wave_sum(q);
+			q = group_sum<LPR>(q);
 			rstd = rsqrtf(q * inv_d + eps);
 		}
-		if (lane == 0) {
+		if (l == 0 && live) {
 			if (!RMS) mean_out[row] = mu;
 			rstd_out[row] = rstd;
 		}
 #pragma unroll
 		for (int it = 0; it < ITERS; ++it) {
-			const int c = lane + it * 64;
-			if (c < nchunk) {
+			const int c = l + it * LPR;
+			if (live && c < nchunk) {
 				float g[VEC], o[VEC];
 				load_vec<float, VEC>(gamma + c * VEC, g);
 				if (RMS) {
@@ -86,15 +99,17 @@ __global__ __launch_bounds__(256) void norm_fwd_kernel(const T* __restrict__ x, 
 
 constexpr int BWD_THREADS = 768;  // 12 waves = 3 per SIMD (170 registers each), ONE workgroup per CU: every workgroup ends with a float atomic per column into dgamma / dbeta, and atomics from different XCDs on one address serialise at the memory side (768 workgroups spent 30 of 77 us there)
 
-template <typename T, int VEC, int ITERS, bool RMS>
+template <typename T, int VEC, int ITERS, bool RMS, int LPR>
 __global__ __launch_bounds__(BWD_THREADS) void norm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
 	const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ rstd_in,
-	const T* __restrict__ dres, T* __restrict__ dx, float* dgamma, float* dbeta, int64_t rows, int d, float offset) {
+	const T* __restrict__ dres, T* __restrict__ dx, float* dgamma, float* dbeta, float* partials, int64_t rows, int d, float offset) {
 	extern __shared__ __attribute__((aligned(16))) float red[];  // [2][d]
+	constexpr int RPW = 64 / LPR;  // rows per wavefront
 	const int lane = threadIdx.x & 63;
 	const int wave = threadIdx.x >> 6;
+	const int l = lane % LPR, sub = lane / LPR;
 	constexpr int WAVES = BWD_THREADS / 64;
-	const int64_t nwaves = (int64_t)gridDim.x * WAVES;
+	const int64_t nwaves = (int64_t)gridDim.x * WAVES * RPW;  // rows between two rows of one lane group
 	const int nchunk = d / VEC;
 	const float inv_d = 1.0f / (float)d;
 	for (int i = threadIdx.x; i < 2 * d; i += BWD_THREADS) red[i] = 0.f;
@@ -104,7 +119,7 @@ __global__ __launch_bounds__(BWD_THREADS) void norm_bwd_kernel(const T* __restri
 	float accg[ITERS][VEC], accb[ITERS][VEC];
 #pragma unroll
 	for (int it = 0; it < ITERS; ++it) {
-		const int c = lane + it * 64;
+		const int c = l + it * LPR;
 #pragma unroll
 		for (int j = 0; j < VEC; ++j) {
 			accg[it][j] = 0.f;
@@ -134,7 +149,7 @@ __global__ __launch_bounds__(BWD_THREADS) void norm_bwd_kernel(const T* __restri
 		p.rs = rstd_in[row];
 #pragma unroll
 		for (int it = 0; it < ITERS; ++it) {
-			const int c = lane + it * 64;
+			const int c = l + it * LPR;
 			if (c < nchunk) {
 				p.x[it] = *reinterpret_cast<const Pack<T, VEC>*>(x + row * d + c * VEC);
 				p.dy[it] = *reinterpret_cast<const Pack<T, VEC>*>(dy + row * d + c * VEC);
@@ -144,6 +159,7 @@ __global__ __launch_bounds__(BWD_THREADS) void norm_bwd_kernel(const T* __restri
 	};
 	// works on row `row`, whose operands are in p, and refills p with row `next`
 	auto work = [&](Pre& p, int64_t row, int64_t next) {
+		const bool live = row < rows;  // (the loop runs on the wavefront's first row: its other lane groups may be past the end)
 		const float mu = p.mu, rs = p.rs;
 		float xh[ITERS][VEC], g[ITERS][VEC], rres[ITERS][VEC], dyv[ITERS][VEC];
 #pragma unroll
@@ -159,8 +175,8 @@ __global__ __launch_bounds__(BWD_THREADS) void norm_bwd_kernel(const T* __restri
 		float s1 = 0.f, s2 = 0.f;
 #pragma unroll
 		for (int it = 0; it < ITERS; ++it) {
-			const int c = lane + it * 64;
-			if (c < nchunk) {
+			const int c = l + it * LPR;
+			if (live && c < nchunk) {
 #pragma unroll
 				for (int j = 0; j < VEC; ++j) {
 					xh[it][j] = (xh[it][j] - mu) * rs;
@@ -178,12 +194,12 @@ __global__ __launch_bounds__(BWD_THREADS) void norm_bwd_kernel(const T* __restri
 				}
 			}
 		}
-		s2 = wave_sum(s2) * inv_d;
-		s1 = RMS ? 0.f : wave_sum(s1) * inv_d;
+		s2 = group_sum<LPR>(s2) * inv_d;
+		s1 = RMS ? 0.f : group_sum<LPR>(s1) * inv_d;
 #pragma unroll
 		for (int it = 0; it < ITERS; ++it) {
-			const int c = lane + it * 64;
-			if (c < nchunk) {
+			const int c = l + it * LPR;
+			if (live && c < nchunk) {
 				float o[VEC];
 #pragma unroll
 				for (int j = 0; j < VEC; ++j) o[j] = (g[it][j] - s1 - xh[it][j] * s2) * rs;
@@ -195,18 +211,28 @@ __global__ __launch_bounds__(BWD_THREADS) void norm_bwd_kernel(const T* __restri
 			}
 		}
 	};
-	const int64_t row0 = (int64_t)blockIdx.x * WAVES + wave;
-	fetch(pa, row0);
-	fetch(pb, row0 + nwaves);
-	for (int64_t row = row0; row < rows; row += 2 * nwaves) {
+	const int64_t base0 = ((int64_t)blockIdx.x * WAVES + wave) * RPW;
+	fetch(pa, base0 + sub);
+	fetch(pb, base0 + sub + nwaves);
+	for (int64_t base = base0; base < rows; base += 2 * nwaves) {
+		const int64_t row = base + sub;
 		work(pa, row, row + 2 * nwaves);
-		if (row + nwaves < rows) work(pb, row + nwaves, row + 3 * nwaves);
+		if (base + nwaves < rows) work(pb, row + nwaves, row + 3 * nwaves);
 	}
-	// column sums: waves of the block combine in LDS, then one float atomic per column per block
+	// column sums: the lane groups of a wave combine by shuffles, the waves of the block in LDS, then one float atomic
+	// per column per block
 #pragma unroll
 	for (int it = 0; it < ITERS; ++it) {
-		const int c = lane + it * 64;
-		if (c < nchunk) {
+		const int c = l + it * LPR;
+#pragma unroll
+		for (int j = 0; j < VEC; ++j) {
+#pragma unroll
+			for (int o = LPR; o < 64; o <<= 1) {
+				accg[it][j] += __shfl_xor(accg[it][j], o, 64);
+				if (!RMS) accb[it][j] += __shfl_xor(accb[it][j], o, 64);
+			}
+		}
+		if (sub == 0 && c < nchunk) {
 #pragma unroll
 			for (int j = 0; j < VEC; ++j) {
 				atomicAdd(&red[c * VEC + j], accg[it][j]);
@@ -215,13 +241,41 @@ __global__ __launch_bounds__(BWD_THREADS) void norm_bwd_kernel(const T* __restri
 		}
 	}
 	__syncthreads();
-	// every workgroup starts at another column, so workgroups that finish together do not queue on the same addresses
+	if (partials != nullptr) {
+		// this workgroup's column sums as one row of [gridDim.x][2 * d]; norm_bwd_reduce_kernel adds the rows up
+		const int n = RMS ? d : 2 * d;
+		for (int i = threadIdx.x; i < n; i += BWD_THREADS) partials[(int64_t)blockIdx.x * 2 * d + i] = red[i];
+		return;
+	}
+	// no scratch: float atomics.  (Atomics from different XCDs on one address serialise at the memory side, about 40 ns
+	// each: 256 workgroups end with a 10 us tail.)  Every workgroup starts at another column, so workgroups that finish
+	// together do not queue on the same addresses.
 	const int rot = (int)((blockIdx.x * 61u) % (unsigned)d);
 	for (int i = threadIdx.x; i < d; i += BWD_THREADS) {
 		int c = i + rot;
 		if (c >= d) c -= d;
 		atomicAdd(&dgamma[c], red[c]);
 		if (!RMS) atomicAdd(&dbeta[c], red[d + c]);
+	}
+}
+
+// dgamma[c] += sum over b of partials[b][c], dbeta[c] += sum over b of partials[b][d + c] (ncol = 2 * d; RMSNorm: ncol = d):
+// 32 columns x 8 row lanes per workgroup, the 8 partial sums of a column combined in LDS.  One writer per column.
+__global__ __launch_bounds__(256) void norm_bwd_reduce_kernel(const float* __restrict__ partials, int nblocks, int d, int ncol, float* dgamma, float* dbeta) {
+	__shared__ float sm[8][33];
+	const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
+	const int c = blockIdx.x * 32 + cx;
+	float s = 0.f;
+	if (c < ncol) {
+		for (int b = ry; b < nblocks; b += 8) s += partials[(int64_t)b * 2 * d + c];
+	}
+	sm[ry][cx] = s;
+	__syncthreads();
+	if (ry == 0 && c < ncol) {
+#pragma unroll
+		for (int r = 1; r < 8; ++r) s += sm[r][cx];
+		if (c < d) dgamma[c] += s;
+		else dbeta[c - d] += s;
 	}
 }
 
@@ -344,33 +398,67 @@ struct NormArgs {
 	const float *gamma, *beta, *mean_in, *rstd_in;
 	void *y, *sum_out, *dx;
 	float *mean, *rstd, *dgamma, *dbeta;
+	void* workspace;  // backward: room for the per-workgroup column sums, or null
+	int64_t workspace_bytes;
 	int64_t rows;
 	int d;
 	float eps, offset;
 };
 
-template <typename T, int VEC, int ITERS, bool RMS>
+template <typename T, int VEC, int ITERS, bool RMS, int LPR = 64>
 int launch_fwd(const NormArgs& a, hipStream_t st) {
-	int grid = (int)std::min<int64_t>(vitk_cdiv(a.rows, 4), 8192);
-	hipLaunchKernelGGL((norm_fwd_kernel<T, VEC, ITERS, RMS>), dim3(grid), dim3(256), 0, st, (const T*)a.x, (const T*)a.res, a.gamma, a.beta,
+	int grid = (int)std::min<int64_t>(vitk_cdiv(a.rows, 4 * (64 / LPR)), 8192);
+	hipLaunchKernelGGL((norm_fwd_kernel<T, VEC, ITERS, RMS, LPR>), dim3(grid), dim3(256), 0, st, (const T*)a.x, (const T*)a.res, a.gamma, a.beta,
 		(T*)a.y, (T*)a.sum_out, a.mean, a.rstd, a.rows, a.d, a.eps, a.offset);
 	VITK_CHECK_LAUNCH();
 	return VITK_OK;
 }
-template <typename T, int VEC, int ITERS, bool RMS>
+template <typename T, int VEC, int ITERS, bool RMS, int LPR = 64>
 int launch_bwd(const NormArgs& a, hipStream_t st) {
-	int grid = (int)std::min<int64_t>(vitk_cdiv(a.rows, BWD_THREADS / 64), 256);
+	int grid = (int)std::min<int64_t>(vitk_cdiv(a.rows, (BWD_THREADS / 64) * (64 / LPR)), 256);
 	size_t lds = (size_t)2 * a.d * sizeof(float);
-	hipLaunchKernelGGL((norm_bwd_kernel<T, VEC, ITERS, RMS>), dim3(grid), dim3(BWD_THREADS), lds, st, (const T*)a.dy, (const T*)a.x, a.gamma, a.mean_in,
-		a.rstd_in, (const T*)a.dres, (T*)a.dx, a.dgamma, a.dbeta, a.rows, a.d, a.offset);
+	float* partials = nullptr;
+	if (a.workspace != nullptr && vitk_aligned(a.workspace, 16) && a.workspace_bytes >= (int64_t)grid * 2 * a.d * (int64_t)sizeof(float))
+		partials = reinterpret_cast<float*>(a.workspace);
+	hipLaunchKernelGGL((norm_bwd_kernel<T, VEC, ITERS, RMS, LPR>), dim3(grid), dim3(BWD_THREADS), lds, st, (const T*)a.dy, (const T*)a.x, a.gamma, a.mean_in,
+		a.rstd_in, (const T*)a.dres, (T*)a.dx, a.dgamma, a.dbeta, partials, a.rows, a.d, a.offset);
 	VITK_CHECK_LAUNCH();
+	if (partials != nullptr) {
+		const int ncol = RMS ? a.d : 2 * a.d;
+		hipLaunchKernelGGL(norm_bwd_reduce_kernel, dim3((unsigned)vitk_cdiv(ncol, 32)), dim3(256), 0, st, partials, grid, a.d, ncol, a.dgamma, a.dbeta);
+		VITK_CHECK_LAUNCH();
+	}
 	return VITK_OK;
+}
+
+// Rows of at most 1 KB: several rows per wavefront.  The smallest lane group (8, 16 or 32 lanes) that holds the row in at
+// most three chunks per lane; returns 1 (not a status code) when the row does not fit this form.
+template <typename T, bool RMS, bool FWD, int VEC>
+int launch_small_rows(const NormArgs& a, hipStream_t st) {
+	const int nchunk = a.d / VEC;
+	const int lpr = nchunk <= 24 ? 8 : nchunk <= 48 ? 16 : nchunk <= 96 ? 32 : 0;
+	if (a.d % VEC != 0 || lpr == 0) return 1;
+	const int it = (int)vitk_cdiv(nchunk, lpr);
+#define NORM_SMALL(LPR_, IT_) \
+	if (lpr == LPR_ && it == IT_) { \
+		if constexpr (FWD) return launch_fwd<T, VEC, IT_, RMS, LPR_>(a, st); \
+		else return launch_bwd<T, VEC, IT_, RMS, LPR_>(a, st); \
+	}
+	NORM_SMALL(8, 1) NORM_SMALL(8, 2) NORM_SMALL(8, 3) NORM_SMALL(16, 2) NORM_SMALL(16, 3) NORM_SMALL(32, 2) NORM_SMALL(32, 3)
+#undef NORM_SMALL
+	return 1;
 }
 
 template <typename T, bool RMS, bool FWD>
 int dispatch(const NormArgs& a, bool vec_ok, hipStream_t st) {
 	constexpr int V = VecOf<T>::N;
 #define NORM_GO(VEC_, IT_) return FWD ? launch_fwd<T, VEC_, IT_, RMS>(a, st) : launch_bwd<T, VEC_, IT_, RMS>(a, st)
+	static const bool small_rows = getenv("VITK_NO_NORM_SMALL_ROWS") == nullptr;  // A-B switch
+	if (small_rows && vec_ok && (size_t)a.d * sizeof(T) <= 1024) {
+		// (the backward is register-heavy: half-width chunks, as below)
+		const int rc = launch_small_rows<T, RMS, FWD, FWD ? V : V / 2>(a, st);
+		if (rc != 1) return rc;
+	}
 	if (!FWD && vec_ok && a.d % (V / 2) == 0) {
 		// backward (register-heavy): if half-width accesses leave fewer lane slots idle (d = 768: 3 x 64 x 4 exactly,
 		// against 2 x 64 x 8 with a quarter idle), the smaller footprint keeps 4 waves per SIMD resident
@@ -426,9 +514,10 @@ extern "C" int vitk_layernorm_fwd(const void* x, const void* res, const float* g
 }
 
 extern "C" int vitk_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd, const void* dres,
-	void* dx, float* dgamma, float* dbeta, int64_t rows, int64_t d, int dtype, void* stream) {
+	void* dx, float* dgamma, float* dbeta, int64_t rows, int64_t d, int dtype, void* workspace, int64_t workspace_bytes, void* stream) {
 	VITK_REQUIRE(dy && x && gamma && mean && rstd && dx && dgamma && dbeta, VITK_ERR_NULL);
 	NormArgs a{};
+	a.workspace = workspace; a.workspace_bytes = workspace_bytes;
 	a.dy = dy; a.x = x; a.gamma = gamma; a.mean_in = mean; a.rstd_in = rstd; a.dres = dres; a.dx = dx; a.dgamma = dgamma; a.dbeta = dbeta;
 	a.rows = rows; a.d = (int)d; a.offset = 0.f;
 	return run<false, false>(a, dtype, (hipStream_t)stream);
@@ -445,9 +534,10 @@ extern "C" int vitk_rmsnorm_fwd(const void* x, const void* res, const float* wei
 }
 
 extern "C" int vitk_rmsnorm_bwd(const void* dy, const void* x, const float* weight, const float* rstd, const void* dres, void* dx,
-	float* dweight, int64_t rows, int64_t d, int unit_offset, int dtype, void* stream) {
+	float* dweight, int64_t rows, int64_t d, int unit_offset, int dtype, void* workspace, int64_t workspace_bytes, void* stream) {
 	VITK_REQUIRE(dy && x && weight && rstd && dx && dweight, VITK_ERR_NULL);
 	NormArgs a{};
+	a.workspace = workspace; a.workspace_bytes = workspace_bytes;
 	a.dy = dy; a.x = x; a.gamma = weight; a.rstd_in = rstd; a.dres = dres; a.dx = dx; a.dgamma = dweight;
 	a.rows = rows; a.d = (int)d; a.offset = unit_offset ? 1.f : 0.f;
 	return run<true, false>(a, dtype, (hipStream_t)stream);

@@ -394,9 +394,10 @@ def norm_fwd(x, weight, bias, kind, eps, unit_offset=True, res=None):
 	return y, s, None, rstd
 
 
-def norm_bwd(dy, x, weight, mean, rstd, kind, unit_offset=True, dres=None, dw_out=None, db_out=None):
+def norm_bwd(dy, x, weight, mean, rstd, kind, unit_offset=True, dres=None, dw_out=None, db_out=None, workspace=True):
 	"""Returns (dx, dweight_f32, dbias_f32_or_None); dres (same shape as x) is added into dx.  dw_out / db_out: float32
-	[d] buffers the kernel accumulates into instead of fresh zeroed ones (gradient sinks)."""
+	[d] buffers the kernel accumulates into instead of fresh zeroed ones (gradient sinks).  workspace=False: the column
+	sums are added with float atomics instead of passing through the scratch buffer."""
 	rows, d = x.shape
 	assert dy.is_contiguous() and x.is_contiguous() and (dres is None or dres.is_contiguous())
 	dx = torch.empty_like(x)
@@ -409,11 +410,18 @@ def norm_bwd(dy, x, weight, mean, rstd, kind, unit_offset=True, dres=None, dw_ou
 		dbuf = db_out if db_out is not None else dwb[1]
 	lib = L.load()
 	dt = L.dtype_code(x.dtype)
+	# the per-workgroup column sums pass through the scratch buffer (stream-ordered with the GEMMs that use it)
+	ws_ptr, ws_bytes = 0, 0
+	if workspace:
+		ws = gemm_workspace(x.device)
+		ws_ptr, ws_bytes = ws.data_ptr(), ws.numel()
 	if kind == "layernorm":
 		db = dbuf
-		L.check(lib.vitk_layernorm_bwd(L.ptr(dy), L.ptr(x), L.ptr(weight), L.ptr(mean), L.ptr(rstd), L.ptr(dres), L.ptr(dx), L.ptr(dw), L.ptr(db), rows, d, dt, L.stream()))
+		L.check(lib.vitk_layernorm_bwd(L.ptr(dy), L.ptr(x), L.ptr(weight), L.ptr(mean), L.ptr(rstd), L.ptr(dres), L.ptr(dx), L.ptr(dw), L.ptr(db), rows, d, dt,
+			ws_ptr, ws_bytes, L.stream()))
 		return dx, dw, db
-	L.check(lib.vitk_rmsnorm_bwd(L.ptr(dy), L.ptr(x), L.ptr(weight), L.ptr(rstd), L.ptr(dres), L.ptr(dx), L.ptr(dw), rows, d, int(unit_offset), dt, L.stream()))
+	L.check(lib.vitk_rmsnorm_bwd(L.ptr(dy), L.ptr(x), L.ptr(weight), L.ptr(rstd), L.ptr(dres), L.ptr(dx), L.ptr(dw), rows, d, int(unit_offset), dt,
+		ws_ptr, ws_bytes, L.stream()))
 	return dx, dw, None
 
 
@@ -798,12 +806,21 @@ class PatchEmbedFn(torch.autograd.Function):
 		K = w.shape[1]
 		x = torch.empty((Bn, P2 + lead, d), dtype=dt, device=images.device)
 		pos = f32(pos_embed).reshape(P2 + lead, d)
-		gemm(img, weight_as(w, dt), x, Bn * P2, d, K, K, K, d, bias=f32(b), patch=(n_patch, C, H), tokens_per_image=P2, pos=pos, lead_rows=lead)
 		lib, dtc = L.load(), L.dtype_code(dt)
+		patches = None
+		if dt == torch.bfloat16 and (H // n_patch) % 8 != 0:
+			# the bf16 MFMA kernels gather patches by 16-byte pieces of a pixel row; narrower patches (4 x 4 on 32 x 32 inputs)
+			# are laid out as rows first (a few MB, kept for the weight gradient) and take the plain MFMA GEMM
+			patches = torch.empty((Bn * P2, K), dtype=dt, device=images.device)
+			L.check(lib.vitk_patchify(L.ptr(img), L.ptr(patches), Bn, C, H, n_patch, dtc, L.stream()))
+			gemm(patches, weight_as(w, dt), x, Bn * P2, d, K, K, K, d, bias=f32(b), tokens_per_image=P2, pos=pos, lead_rows=lead)
+		else:
+			gemm(img, weight_as(w, dt), x, Bn * P2, d, K, K, K, d, bias=f32(b), patch=(n_patch, C, H), tokens_per_image=P2, pos=pos, lead_rows=lead)
 		L.check(lib.vitk_cls_rows(L.ptr(x), L.ptr(f32(class_token)), L.ptr(pos), Bn, P2 + lead, d, dtc, L.stream()))
 		if dist_token is not None:  # row 1 of every image: the same kernel on the buffers shifted by one row
 			L.check(lib.vitk_cls_rows(x.data_ptr() + d * x.element_size(), L.ptr(f32(dist_token)), pos.data_ptr() + 4 * d, Bn, P2 + lead, d, dtc, L.stream()))
 		ctx.save_for_backward(img, w)
+		ctx.patches = patches
 		ctx.meta = (images.shape, images.dtype, b, class_token, pos_embed, n_patch, dt, dist_token)
 		return x
 
@@ -833,8 +850,10 @@ class PatchEmbedFn(torch.autograd.Function):
 		ddist = None if dist_token is None else lead_row_grad("dist", dist_token, 1)
 		dtok = torch.empty((Bn * P2, d), dtype=dt, device=dx.device)
 		L.check(lib.vitk_drop_lead_rows(L.ptr(dx), L.ptr(dtok), Bn, S, d, lead, dtc, L.stream()))
-		patches = torch.empty((Bn * P2, K), dtype=dt, device=dx.device)
-		L.check(lib.vitk_patchify(L.ptr(img), L.ptr(patches), Bn, C, H, n_patch, dtc, L.stream()))
+		patches = ctx.patches
+		if patches is None:
+			patches = torch.empty((Bn * P2, K), dtype=dt, device=dx.device)
+			L.check(lib.vitk_patchify(L.ptr(img), L.ptr(patches), Bn, C, H, n_patch, dtc, L.stream()))
 		dw, db = linear_wgrad(dtok, patches, bias_grad=True, dw_out=sk.buf("w"), db_out=sk.buf("b"))
 		dimg = None
 		if ctx.needs_input_grad[0]:
