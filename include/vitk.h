@@ -253,6 +253,17 @@ int vitk_act_bwd(const void* dy, const void* x, void* dx, int64_t n, int act, in
  * The random stream differs from torch's Philox stream, so training-mode dropout matches the
  * reference in distribution only. */
 int vitk_dropout(const void* x, void* y, int64_t n, float p, uint64_t seed, int dtype, void* stream);
+/* Dropout epoch.  Every mask of this library (vitk_dropout / vitk_dropout_add, the drop_p of vitk_gemm, the dropout_p of
+ * the attention calls) is a function of (seed, element); a launch captured into a HIP graph keeps the seed it was captured
+ * with, so a replayed training step would draw the same masks every time.  vitk_dropout_epoch_set registers, for the
+ * calling thread's current device, one device word (uint32, caller-owned, must outlive every launch made while it is
+ * registered) whose value at execution time is mixed into the seed by every later dropout launch on that device; null
+ * unregisters.  A step that is captured advances the word once, before its first mask (vitk_dropout_epoch_advance: one
+ * tiny kernel on `stream`), so forward and backward of one replay agree and two replays differ.  With nothing
+ * registered, or while the word holds 0, the masks are those of the seed alone.  The reference draws torch's Philox
+ * stream per call (nn.Dropout, layers/vit.py:17-23), which a captured graph advances the same way. */
+int vitk_dropout_epoch_set(const uint32_t* epoch);
+int vitk_dropout_epoch_advance(uint32_t* epoch, void* stream);
 /* y = res + dropout(dropout(x, p1, seed1), p2, seed2): the branch dropout(s) and the residual add of a block in one
  * pass (layers/vit.py:43-47 and 51-55; the feed-forward branch passes through FeedForward.dropout2,
  * layers/transformers.py:55, and ViTBlock.ff_dropout back to back).  res nullable (then y is the dropped x: the

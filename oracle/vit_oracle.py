@@ -222,18 +222,19 @@ def _splitmix64(z):
 	return z ^ (z >> 31)
 
 
-def dropout_multiplier(seed, p, n):
+def dropout_multiplier(seed, p, n, epoch=0):
 	"""nn.Dropout (layers/vit.py:17-23, layers/transformers.py:20-21) as the HIP kernels draw it, for a contiguous tensor of
 	n elements: float64 vector of 0 or 1 / (1 - p'), p' = p quantised to 1/65536.  Elements 2j and 2j+1 take the low and
 	high 16 bits of one 32-bit hash of (seed, j).  The streaming dropout kernels and the GEMM epilogues use this same
 	function (element index = row * N + column).  torch's Philox stream cannot be reproduced, so the tests hand THIS
-	mask to the reference arithmetic."""
+	mask to the reference arithmetic.  epoch: value of the registered dropout-epoch word (a replayed HIP graph advances
+	it per step so that every replay draws new masks from the seeds it was captured with); 0 leaves the seed alone."""
 	import numpy as np
 	if p <= 0.0:
 		return torch.ones(n, dtype=torch.float64)
 	m = np.uint64(0xFFFFFFFF)
 	z = _splitmix64(int(seed) & ((1 << 64) - 1))
-	k0, k1 = np.uint64(z & 0xFFFFFFFF), np.uint64(z >> 32)
+	k0, k1 = np.uint64(z & 0xFFFFFFFF), np.uint64(((z >> 32) + int(epoch) * 0x85EBCA6B) & 0xFFFFFFFF)
 	t = float(np.float32(p) * np.float32(65536.0) + np.float32(0.5))
 	thr = 65535 if t >= 65535.0 else (1 if t < 1.0 else int(t))
 	pair = np.arange((n + 1) // 2, dtype=np.uint64)
@@ -249,17 +250,18 @@ def dropout_multiplier(seed, p, n):
 	return torch.from_numpy(keep)
 
 
-def attn_dropout_keep(seed, p, B, H, Sq, Skv):
+def attn_dropout_keep(seed, p, B, H, Sq, Skv, epoch=0):
 	"""Keep mask of the attention-probability dropout (the `dropout_p` of F.scaled_dot_product_attention,
 	layers/attention.py:41,86), as the HIP kernels generate it: values 0 or 1/(1 - p'), shape [B, H, Sq, Skv], with
 	p' = p quantised to 1/65536.  The reference draws its mask from torch's Philox stream, which cannot be reproduced;
-	the tests therefore hand THIS mask to the reference arithmetic below (distribution parity, exact arithmetic parity)."""
+	the tests therefore hand THIS mask to the reference arithmetic below (distribution parity, exact arithmetic parity).
+	epoch: as in dropout_multiplier."""
 	import numpy as np
 	m = np.uint64(0xFFFFFFFF)
 	thr = min(int(round(p * 65536.0)), 65535)
 	if p > 0 and thr == 0:
 		thr = 1
-	seed_lo, seed_hi = np.uint64(seed & 0xFFFFFFFF), np.uint64((seed >> 32) & 0xFFFFFFFF)
+	seed_lo, seed_hi = np.uint64(((seed & 0xFFFFFFFF) + int(epoch) * 0x85EBCA6B) & 0xFFFFFFFF), np.uint64((seed >> 32) & 0xFFFFFFFF)
 	bh = np.arange(B * H, dtype=np.uint64)
 	head_key = _hash32(seed_lo ^ _hash32(seed_hi ^ bh))  # [B*H]
 	q = np.arange(Sq, dtype=np.uint64)

@@ -119,6 +119,56 @@ def test_dropout_mask_matches_oracle(gpu, dtype, n, p):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+def test_dropout_epoch(gpu, dtype):
+	"""A registered dropout-epoch word is mixed into the seed of every mask at execution time (what lets a replayed HIP
+	graph draw new masks from the seeds it was captured with): value 0 leaves the masks of the seeds alone; another value
+	gives the masks the oracle restates for that epoch, the same in the streaming kernel, the GEMM epilogue (persistent
+	bf16 kernel and generic kernel) and the attention kernels (whole-key-set, key-blocked and generic), forward and backward."""
+	from vit_amd import ops
+	n, p, seed = 4096, 0.3, 4242
+	x = torch.ones(n, device=gpu).to(dtype)
+	base = O.dropout_multiplier(seed, p, n)
+	ep = ops.DropoutEpoch(gpu)
+	try:
+		assert torch.equal(ops.dropout_add(x, None, p, seed).cpu().double() != 0, base != 0)
+		ep.advance()
+		ep.advance()
+		torch.cuda.synchronize()
+		assert int(ep.word[0]) == 2
+		want = O.dropout_multiplier(seed, p, n, epoch=2)
+		assert not torch.equal(want != 0, base != 0)
+		assert torch.equal(ops.dropout_add(x, None, p, seed).cpu().double() != 0, want != 0)
+		for M, N, K in ((1024, 1024, 128), (33, 7, 5)):
+			a, ar = rnd((M, K), dtype, gpu, seed=1)
+			w, wr = rnd((N, K), dtype, gpu, 0.1, seed=2)
+			res, rr = rnd((M, N), dtype, gpu, seed=4)
+			m2 = O.dropout_multiplier(seed, p, M * N, epoch=2).reshape(M, N)
+			y = ops.linear_fwd(a, w, None, residual=res, drop=((p, seed),))
+			assert relerr(y, rr + (ar @ wr.t()) * m2) < TOL[dtype]
+		for B, h, Sq, Skv, dh in ((2, 3, 65, 65, 64), (1, 2, 300, 77, 12)):
+			d = h * dh
+			q, qr = rnd((B * Sq, d), dtype, gpu, seed=1)
+			k, kr = rnd((B * Skv, d), dtype, gpu, seed=2)
+			v, vr = rnd((B * Skv, d), dtype, gpu, seed=3)
+			do, dor = rnd((B * Sq, d), dtype, gpu, seed=4)
+			keep = O.attn_dropout_keep(seed, p, B, h, Sq, Skv, epoch=2)
+			assert not torch.equal(keep != 0, O.attn_dropout_keep(seed, p, B, h, Sq, Skv) != 0)
+			out, lse = ops.attention_fwd(q, k, v, B, h, Sq, Skv, dh, drop=(p, seed))
+			q4, k4, v4 = (O.split_heads(t.reshape(B, -1, d), h) for t in (qr, kr, vr))
+			o_ref, lse_ref = O.sdpa_dropout_fwd(q4, k4, v4, keep)
+			assert relerr(out, O.merge_heads(o_ref).reshape(B * Sq, d)) < TOL[dtype]
+			dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+			ops.attention_bwd(do, q, k, v, out, lse, dq, dk, dv, B, h, Sq, Skv, dh, drop=(p, seed))
+			dq_r, dk_r, dv_r = O.sdpa_dropout_bwd(O.split_heads(dor.reshape(B, Sq, d), h), q4, k4, v4, o_ref, lse_ref, keep)
+			assert relerr(dq, O.merge_heads(dq_r).reshape(B * Sq, d)) < TOL[dtype]
+			assert relerr(dk, O.merge_heads(dk_r).reshape(B * Skv, d)) < TOL[dtype]
+			assert relerr(dv, O.merge_heads(dv_r).reshape(B * Skv, d)) < TOL[dtype]
+	finally:
+		ep.close()
+	assert torch.equal(ops.dropout_add(x, None, p, seed).cpu().double() != 0, base != 0)  # unregistered: the seed alone again
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("M,N,K", [(200, 256, 128), (4363, 3848, 128), (1024, 1024, 128), (300, 130, 72), (33, 7, 5)])
 def test_gemm_fused_dropout(gpu, dtype, M, N, K):
 	"""Dropout fused into the GEMM epilogues (activation output, branch before the residual add, gradient in front of

@@ -16,7 +16,7 @@ TOL = {torch.float32: 1e-4, torch.bfloat16: 2e-2}
 GTOL = {torch.float32: 1e-4, torch.bfloat16: 3e-2}
 
 
-def make_vit(c, gpu):
+def make_vit(c, gpu, dropout=0.0):
 	from vit_amd.layers import MHA, LayerNorm, RMSNorm
 	from vit_amd.models import ViT
 
@@ -26,7 +26,7 @@ def make_vit(c, gpu):
 		setattr(Cfg, k, tuple(v) if isinstance(v, list) else v)
 	Cfg.attention = MHA
 	Cfg.norm = nn.LayerNorm if c["norm"] == "layernorm" else RMSNorm
-	Cfg.dropout = 0.0
+	Cfg.dropout = dropout
 	Cfg.use_qk_norm = False
 	return ViT(Cfg()).to(gpu)
 
@@ -452,6 +452,8 @@ def test_graphed_training_step_matches_eager(gpu):
 				sched.step()
 		assert trainer.opt.step_count == 5 and int(trainer.opt.step_state[0]) == 5
 		out = losses, trainer.flat.param.clone(), lrs
+		if g is not None:
+			g.close()
 		trainer.close()
 		return out
 
@@ -463,6 +465,38 @@ def test_graphed_training_step_matches_eager(gpu):
 	assert relerr(pg, pe.cpu().double()) < 2e-2
 	_, p_const, _ = run(True, scheduled=False)
 	assert relerr(p_const, pe.cpu().double()) > 10 * relerr(pg, pe.cpu().double())  # the schedule did change the replayed updates
+
+
+def test_graphed_step_draws_new_dropout_masks(gpu):
+	"""A captured step with dropout > 0: the seeds are fixed at capture, the device-side epoch word is advanced by the
+	graph itself, so replays on the same batch with frozen weights (lr 0) give different losses, while the same step
+	replayed from the same epoch gives the same loss bit for bit."""
+	from vit_amd import dp, ops
+	c = dict(d_model=64, n_head=1, n_block=2, n_patch=4, d_ff=128, out_d=10, chw=(3, 16, 16), activation="gelu", norm="layernorm",
+		use_layer_scale=False)
+	ops.clear_grad_sinks()
+	torch.manual_seed(0)
+	model = make_vit(c, gpu, dropout=0.2)
+	model.train()
+	trainer = dp.Trainer(model, lr=0.0, weight_decay=0.0)
+	gen = torch.Generator().manual_seed(5)
+	x = torch.randn(8, 3, 16, 16, generator=gen).to(gpu)
+	y = torch.randint(0, 10, (8,), generator=gen).to(gpu)
+
+	def loss_fn(xi, yi):
+		with torch.autocast("cuda", dtype=torch.bfloat16):
+			return ops.cross_entropy(model(xi), yi)
+	g = dp.GraphedStep(trainer, loss_fn, [x, y], warmup=3)
+	try:
+		losses = [float(g(x, y)) for _ in range(4)]
+		torch.cuda.synchronize()
+		assert int(g.epoch.word[0]) == 4
+		assert len(set(losses)) == 4, losses
+		g.epoch.set(1)  # the second replay's epoch again
+		assert float(g(x, y)) == losses[1]
+	finally:
+		g.close()
+		trainer.close()
 
 
 def test_stale_weight_copies_are_refreshed_or_refused(gpu):

@@ -51,6 +51,8 @@ SIGNATURES = {
 	"vitk_gemm_last_kernel": [],
 	"vitk_gemm_workspace_bytes": [],
 	"vitk_layernorm_fwd": [P, P, P, P, P, P, P, P, I64, I64, FL, I, P],
+	"vitk_dropout_epoch_set": [P],
+	"vitk_dropout_epoch_advance": [P, P],
 	"vitk_layernorm_bwd": [P, P, P, P, P, P, P, P, P, I64, I64, I, P, I64, P],
 	"vitk_rmsnorm_fwd": [P, P, P, P, P, P, I64, I64, FL, I, I, P],
 	"vitk_rmsnorm_bwd": [P, P, P, P, P, P, P, I64, I64, I, I, P, I64, P],

@@ -16,6 +16,7 @@ struct AttnArgs {
 	// ones are scaled by drop_scale = 65536 / (65536 - drop_thr16)
 	uint32_t drop_thr16, seed_lo, seed_hi;
 	float drop_scale;
+	const uint32_t* drop_epoch;  // device word mixed into the seed (see DropKey::epoch), or null
 	float* bwd_scratch;  // backward: [2][B * n_head * Sq] floats (lse in log2 units, delta = rowsum(dO o O)): dQ kernel -> dK/dV kernel
 	int heads_per_wg;  // set by the launcher: consecutive (batch, head) pairs one workgroup of the forward kernel walks
 };
@@ -29,6 +30,10 @@ __host__ __device__ __forceinline__ uint32_t vitk_hash32(uint32_t x) {
 	x *= 0x846ca68bu;
 	x ^= x >> 16;
 	return x;
+}
+// once per kernel, on the kernel's own argument block, before the first mask (see drop_key_enter)
+__device__ __forceinline__ void attn_enter(AttnArgs& a) {
+	if (a.drop_thr16 != 0u && a.drop_epoch != nullptr) a.seed_lo += drop_epoch_term(a.drop_epoch);
 }
 __device__ __forceinline__ uint32_t attn_head_key(const AttnArgs& a, int bh) { return vitk_hash32(a.seed_lo ^ vitk_hash32(a.seed_hi ^ (uint32_t)bh)); }
 __device__ __forceinline__ uint32_t attn_row_key(uint32_t head_key, int q) { return vitk_hash32(head_key + (uint32_t)q * 0x9E3779B1u); }

@@ -24,6 +24,7 @@ static int set_dropout(AttnArgs& a, float dropout_p, uint64_t seed) {
 	a.drop_scale = 65536.f / (float)(65536u - thr);
 	a.seed_lo = (uint32_t)seed;
 	a.seed_hi = (uint32_t)(seed >> 32);
+	a.drop_epoch = thr != 0 ? vitk_dropout_epoch_current() : nullptr;
 	return VITK_OK;
 }
 

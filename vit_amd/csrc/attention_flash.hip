@@ -120,6 +120,7 @@ __device__ __forceinline__ void store4(bf16_t* row, int d0, int dh, const f32x4&
 // probabilities, the mask regenerated from a hash of (seed, batch * n_head + head, query, key pair) as in the other families
 template <int KS, int NDT, bool DROP>
 __global__ __launch_bounds__(256) void attn_flash_fwd_kernel(AttnArgs a) {
+	if constexpr (DROP) attn_enter(a);
 	__shared__ __attribute__((aligned(16))) char smem[3 * IMG];
 	char *Qs = smem, *Ks = smem + IMG, *Vs = smem + 2 * IMG;
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4;
@@ -217,6 +218,7 @@ __global__ __launch_bounds__(256) void attn_flash_fwd_kernel(AttnArgs a) {
 // ---- backward, dQ: one wave = 16 queries; also leaves lse (log2 units) and delta = rowsum(dO o O) in the scratch --------
 template <int KS, int NDT, bool DROP>
 __global__ __launch_bounds__(256) void attn_flash_dq_kernel(AttnArgs a) {
+	if constexpr (DROP) attn_enter(a);
 	__shared__ __attribute__((aligned(16))) char smem[4 * IMG];
 	char *Qs = smem, *Gs = smem + IMG, *Ks = smem + 2 * IMG, *Vs = smem + 3 * IMG;  // Ks doubles as the O image first
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4;
@@ -308,6 +310,7 @@ __global__ __launch_bounds__(256) void attn_flash_dq_kernel(AttnArgs a) {
 // ---- backward, dK / dV: one wave = 16 keys, summed over all query blocks ------------------------------------------------
 template <int KS, int NDT, bool DROP>
 __global__ __launch_bounds__(256) void attn_flash_dkv_kernel(AttnArgs a) {
+	if constexpr (DROP) attn_enter(a);
 	__shared__ __attribute__((aligned(16))) char smem[4 * IMG + 3 * 64 * 4];
 	char *Ks = smem, *Vs = smem + IMG, *Qs = smem + 2 * IMG, *Gs = smem + 3 * IMG;
 	float* lse_s = reinterpret_cast<float*>(smem + 4 * IMG);

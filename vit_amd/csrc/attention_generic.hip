@@ -21,6 +21,7 @@ __device__ __forceinline__ void stage_rows(float (*dst)[DH], const T* src, int64
 
 template <typename T, int DH>
 __global__ __launch_bounds__(64) void attn_fwd_generic_kernel(AttnArgs a) {
+	attn_enter(a);
 	__shared__ float Ks[TK][DH];
 	__shared__ float Vs[TK][DH];
 	const int b = blockIdx.z, h = blockIdx.y;
@@ -84,6 +85,7 @@ __global__ __launch_bounds__(64) void attn_fwd_generic_kernel(AttnArgs a) {
 // dQ: lane = query.  q and dO rows live in LDS with a padded stride so each lane reads its own row conflict-free.
 template <typename T, int DH>
 __global__ __launch_bounds__(64) void attn_bwd_dq_kernel(AttnArgs a) {
+	attn_enter(a);
 	__shared__ float Ks[TK][DH];
 	__shared__ float Vs[TK][DH];
 	__shared__ float Qs[64][DH + 1];
@@ -145,6 +147,7 @@ __global__ __launch_bounds__(64) void attn_bwd_dq_kernel(AttnArgs a) {
 // dK, dV: lane = key.  Q, dO, O are streamed in 32-query tiles.
 template <typename T, int DH>
 __global__ __launch_bounds__(64) void attn_bwd_dkv_kernel(AttnArgs a) {
+	attn_enter(a);
 	__shared__ float Qs[TK][DH];
 	__shared__ float Gs[TK][DH];
 	__shared__ float Ks[64][DH + 1];

@@ -106,6 +106,7 @@ __device__ __forceinline__ void stage_image_dma(char* img, const bf16_t* src, in
 // everything else left out, the staging and launch skeleton alone took 100 of that kernel's 130 us on ViT-B/16.)
 template <int KT2, bool DROP>  // keys padded to 32 * KT2; DROP: attention-probability dropout
 __global__ __launch_bounds__(1024) void attn_fwd_mfma_kernel(AttnArgs a) {
+	if constexpr (DROP) attn_enter(a);
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 	constexpr int IMG = KT2 * 32 * 128;  // one image
 	const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nwaves = blockDim.x >> 6;
@@ -231,6 +232,7 @@ __global__ __launch_bounds__(1024) void attn_fwd_mfma_kernel(AttnArgs a) {
 // ---------------------------------------------------------------------------------------------------------------
 template <int KT2, bool DROP>
 __global__ __launch_bounds__(1024) void attn_bwd_dq_mfma_kernel(AttnArgs a) {
+	if constexpr (DROP) attn_enter(a);
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 	char* Ks = smem;
 	char* Vs = smem + KT2 * 32 * 128;
@@ -355,6 +357,7 @@ __device__ __forceinline__ uint32_t lds_addr(const char* p) {
 // spills, and is slower than the plain kernel it replaced: 176 -> 137 us per ViT-B/16 layer needs the registers.)
 template <int QT2, bool DROP>  // queries padded to 32 * QT2
 __global__ __launch_bounds__(512) void attn_bwd_dkv_mfma_kernel(AttnArgs a) {
+	if constexpr (DROP) attn_enter(a);
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 	constexpr int QP = QT2 * 32, IMG = QP * 128;
 	constexpr int QF = (QP + 63) & ~63;

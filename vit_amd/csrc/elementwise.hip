@@ -10,6 +10,7 @@ namespace {
 // F: float f(float a, float b, int64 index).  b is read only if B != nullptr.
 template <typename TA, typename TB, typename TO, int VEC, typename F>
 __global__ __launch_bounds__(256) void map2_kernel(const TA* __restrict__ a, const TB* __restrict__ b, TO* __restrict__ o, int64_t n, F f) {
+	f.enter();
 	const int64_t stride = (int64_t)gridDim.x * blockDim.x * VEC;
 	for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * VEC; i < n; i += stride) {
 		float va[VEC], vb[VEC], vo[VEC];
@@ -37,14 +38,17 @@ int launch_map2(const void* a, const void* b, void* o, int64_t n, F f, hipStream
 
 struct Ident {
 	__device__ float operator()(float a, float, int64_t) const { return a; }
+	__device__ void enter() {}
 };
 struct ActF {
 	int act;
 	__device__ float operator()(float a, float, int64_t) const { return act_apply(a, act); }
+	__device__ void enter() {}
 };
 struct ActB {
 	int act;
 	__device__ float operator()(float dy, float x, int64_t) const { return dy * act_deriv(x, act); }
+	__device__ void enter() {}
 };
 
 // ---- dropout: the shared counter-based mask (drop_keep in vitk_common.h) ---------------------------
@@ -52,6 +56,7 @@ struct DropF {
 	DropKey key;
 	float inv_keep;
 	__device__ float operator()(float a, float, int64_t i) const { return drop_keep(key, (uint64_t)i) ? a * inv_keep : 0.f; }
+	__device__ void enter() { drop_key_enter(key); }
 };
 static inline DropF make_drop(float p, uint64_t seed) {
 	const DropKey k = make_drop_key(p, seed);
@@ -66,6 +71,10 @@ struct DropAddF {
 		float v = d1(a, 0.f, i);
 		if (two) v = d2(v, 0.f, i);
 		return res + v;
+	}
+	__device__ void enter() {
+		d1.enter();
+		d2.enter();
 	}
 };
 
@@ -495,6 +504,7 @@ extern "C" int vitk_transpose(const void* x, void* y, int64_t rows, int64_t cols
 struct ScaleByDev {
 	const float* g;
 	__device__ float operator()(float a, float, int64_t) const { return a * g[0]; }
+	__device__ void enter() {}
 };
 
 extern "C" int vitk_scale_by(const void* x, const float* g, void* y, int64_t n, int dtype, void* stream) {

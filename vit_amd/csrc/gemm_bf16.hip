@@ -162,6 +162,7 @@ __device__ __forceinline__ void store_frag(const BfArgs& a, int64_t m, int64_t n
 template <int ALAYOUT, int BLAYOUT, bool PATCH, typename TOUT>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(BfArgs a) {
 	extern __shared__ __attribute__((aligned(16))) char smem[];
+	gemm_dev_enter(a.g);
 	const GemmDev& g = a.g;
 	const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 	const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;

@@ -263,6 +263,7 @@ __device__ __forceinline__ void store4(const BigArgs& a, int64_t m, int64_t nb, 
 template <int ALAYOUT, int BLAYOUT, typename TOUT, int EPI, int ACT>
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_256_kernel(BigArgs a) {
 	extern __shared__ __attribute__((aligned(16))) char smem[];
+	gemm_dev_enter(a.g);
 	const GemmDev& g = a.g;
 	const int tid = threadIdx.x, lane = tid & 63;
 	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -667,6 +668,7 @@ __device__ __forceinline__ void epilogue_wave_private(const BigArgs& a, const f3
 template <int ALAYOUT, int BLAYOUT, int EPI, int ACT>
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_256p_kernel(BigArgs a) {
 	extern __shared__ __attribute__((aligned(16))) char smem[];
+	gemm_dev_enter(a.g);
 	const GemmDev& g = a.g;
 	const int tid = threadIdx.x, lane = tid & 63;
 	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);

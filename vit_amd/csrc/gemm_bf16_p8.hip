@@ -84,6 +84,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_p8_kernel(P8Args a) {
 	// memory operations an epilogue issues at least (per wave-lane: 16 output stores, + 16 operand loads with an aux operand)
 	constexpr int N_EPI = (EPI == VITK_EPI_RESIDUAL || EPI == VITK_EPI_ACTGRAD) ? 32 : 16;
 	extern __shared__ __attribute__((aligned(16))) char smem[];
+	gemm_dev_enter(a.g);
 	const GemmDev& g = a.g;
 	const int tid = threadIdx.x, lane = tid & 63;
 	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);

@@ -95,6 +95,7 @@ long long* g_t128_stamps = nullptr;
 template <int EPI, int ACT>
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_t128_kernel(T128Args a) {
 	extern __shared__ __attribute__((aligned(16))) char smem[];
+	gemm_dev_enter(a.g);
 	const GemmDev& g = a.g;
 	const int tid = threadIdx.x, lane = tid & 63;
 	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);

@@ -66,6 +66,12 @@ __device__ __forceinline__ int64_t patch_offset(const GemmDev& g, int64_t m, int
 	return ((b * g.img_c + c) * hw + (py * p + i)) * (int64_t)hw + (px * p + j);
 }
 
+// once per kernel, on the kernel's own argument block, before the first mask (see drop_key_enter)
+__device__ __forceinline__ void gemm_dev_enter(GemmDev& g) {
+	drop_key_enter(g.drop[0]);
+	drop_key_enter(g.drop[1]);
+}
+
 __device__ __forceinline__ int64_t out_row(const GemmDev& g, int64_t m) { return g.tpi > 0 ? m + (m / g.tpi + 1) * g.lead : m; }
 
 // Fused dropout: multipliers (0 or g.drop_scale) of the N consecutive elements (m, n0 .. n0 + N - 1); the mask is

@@ -26,6 +26,7 @@ __device__ __forceinline__ float load_b(const GemmDev& g, int64_t n, int k) {
 // partial sums into C with float atomics (float32 output without epilogue only; C holds the value to add to).
 template <typename TIN, typename TOUT>
 __global__ __launch_bounds__(256) void gemm_generic_kernel(GemmDev g, int k_per_split) {
+	gemm_dev_enter(g);
 	__shared__ float As[BK * LDS_LD];
 	__shared__ float Bs[BK * LDS_LD];
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;

@@ -82,7 +82,13 @@ __device__ __forceinline__ float wave_max(float v) {
 struct DropKey {
 	uint32_t k0, k1;  // the seed, mixed on the host so that consecutive seeds give unrelated masks
 	uint32_t thr16;   // 0 = dropout off
+	// Device word mixed into the seed when the mask is drawn, or null (vitk_dropout_epoch_set): a launch captured into a HIP
+	// graph keeps the seed it was captured with, so a step that is replayed advances this word instead (once per step, before
+	// its first mask) and every replay draws new masks, the forward and the backward of one step the same ones.
+	const uint32_t* epoch;
 };
+// the word registered for the calling thread's current device (null: none)
+const uint32_t* vitk_dropout_epoch_current(void);
 __host__ __device__ __forceinline__ uint64_t vitk_splitmix64(uint64_t z) {
 	z += 0x9E3779B97F4A7C15ull;
 	z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
@@ -90,8 +96,9 @@ __host__ __device__ __forceinline__ uint64_t vitk_splitmix64(uint64_t z) {
 	return z ^ (z >> 31);
 }
 static inline DropKey make_drop_key(float p, uint64_t seed) {
-	DropKey k{0u, 0u, 0u};
+	DropKey k{0u, 0u, 0u, nullptr};
 	if (p > 0.f) {
+		k.epoch = vitk_dropout_epoch_current();
 		const uint64_t z = vitk_splitmix64(seed);
 		k.k0 = (uint32_t)z;
 		k.k1 = (uint32_t)(z >> 32);
@@ -103,8 +110,14 @@ static inline DropKey make_drop_key(float p, uint64_t seed) {
 static inline float drop_key_scale(const DropKey& k) { return 65536.0f / (float)(65536u - k.thr16); }
 // 32 mask bits for elements 2 * pair and 2 * pair + 1 (low / high half)
 // split in two so that callers walking consecutive pairs whose upper index word cannot change hoist the first part
-__host__ __device__ __forceinline__ uint32_t drop_hi_term(const DropKey& k, uint64_t pair) { return k.k1 + (uint32_t)(pair >> 32) * 0x9E3779B1u; }
-__host__ __device__ __forceinline__ uint32_t drop_pair_bits_lo(const DropKey& k, uint32_t hi_term, uint32_t pair_lo) {
+__device__ __forceinline__ uint32_t drop_epoch_term(const uint32_t* epoch) { return epoch != nullptr ? *epoch * 0x85EBCA6Bu : 0u; }
+// Folds the current value of the epoch word into the key.  Every kernel calls this ONCE, at its entry, on its own copy of
+// the key (its by-value argument block): the masks themselves are then drawn from registers only.
+__device__ __forceinline__ void drop_key_enter(DropKey& k) {
+	if (k.thr16 != 0u && k.epoch != nullptr) k.k1 += drop_epoch_term(k.epoch);
+}
+__device__ __forceinline__ uint32_t drop_hi_term(const DropKey& k, uint64_t pair) { return k.k1 + (uint32_t)(pair >> 32) * 0x9E3779B1u; }
+__device__ __forceinline__ uint32_t drop_pair_bits_lo(const DropKey& k, uint32_t hi_term, uint32_t pair_lo) {
 	uint32_t x = pair_lo ^ k.k0;
 	x ^= x >> 16;
 	x *= 0x7feb352du;
@@ -114,10 +127,10 @@ __host__ __device__ __forceinline__ uint32_t drop_pair_bits_lo(const DropKey& k,
 	x ^= x >> 16;
 	return x;
 }
-__host__ __device__ __forceinline__ uint32_t drop_pair_bits(const DropKey& k, uint64_t pair) {
+__device__ __forceinline__ uint32_t drop_pair_bits(const DropKey& k, uint64_t pair) {
 	return drop_pair_bits_lo(k, drop_hi_term(k, pair), (uint32_t)pair);
 }
-__host__ __device__ __forceinline__ bool drop_keep(const DropKey& k, uint64_t i) {
+__device__ __forceinline__ bool drop_keep(const DropKey& k, uint64_t i) {
 	const uint32_t bits = drop_pair_bits(k, i >> 1);
 	return ((i & 1) ? (bits >> 16) : (bits & 0xffffu)) >= k.thr16;
 }

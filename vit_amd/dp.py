@@ -377,9 +377,10 @@ class GraphedStep:
 	must not happen while capturing) run on the example inputs and are then UNDONE: parameters, optimizer moments, step
 	count, module buffers (BatchNorm statistics) and the dropout seed counter are restored, so the first replay is the
 	first training step and the trajectory equals the eager one.  Learning rate and the other hyper-parameters are
-	re-read from the optimizer's param_groups before every replay.  Dropout seeds are host-side values fixed at capture,
-	so a captured step with dropout > 0 replays one mask: use dropout 0 or accept that.  The returned tensors are
-	overwritten by the next call."""
+	re-read from the optimizer's param_groups before every replay.  Dropout seeds are host-side values fixed at capture;
+	the captured step starts by advancing a device word that every mask mixes into its seed (ops.DropoutEpoch), so each
+	replay draws new masks (with dropout > 0 the trajectory equals the eager one in distribution, not mask for mask).  The
+	word stays registered on the device until close().  The returned tensors are overwritten by the next call."""
 
 	def __init__(self, trainer, loss_fn, example_inputs, warmup=3):
 		assert trainer.sync.world == 1, "graph capture of the step is single-process"
@@ -390,6 +391,7 @@ class GraphedStep:
 		saved = [t.clone() for t in (flat.param, opt.m, opt.v, opt.step_state)]
 		bufs = [(b, b.clone()) for b in flat.module.buffers()]
 		saved_steps, saved_seed = opt.step_count, ops.seed_counter()
+		self.epoch = ops.DropoutEpoch(flat.param.device)
 		side = torch.cuda.Stream()
 		side.wait_stream(torch.cuda.current_stream())
 		with torch.cuda.stream(side):  # warm-up off the default stream
@@ -406,9 +408,15 @@ class GraphedStep:
 			b.copy_(src)
 		opt.step_count = saved_steps
 		ops.set_seed_counter(saved_seed)
+		self.epoch.set(0)
 		opt.refresh_copies()
 
+	def close(self):
+		"""Unregister the dropout-epoch word (the captured graph must not be replayed afterwards)."""
+		self.epoch.close()
+
 	def _eager(self):
+		self.epoch.advance()
 		self.trainer.zero_grad()
 		out = self.loss_fn(*self.inputs)
 		loss, logits = out if isinstance(out, tuple) else (out, None)

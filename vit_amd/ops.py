@@ -987,6 +987,37 @@ class DeitDualLossFn(torch.autograd.Function):
 		return scale_by(dc, g), scale_by(dd, g), None, None, None, None, None
 
 
+_epoch_owner = {}  # device index -> the DropoutEpoch registered with the library on that device
+
+
+class DropoutEpoch:
+	"""A device word that every dropout mask drawn on this device mixes into its seed while it is registered
+	(vitk_dropout_epoch_set).  A training step captured into a HIP graph keeps the seeds it was captured with; it calls
+	advance() once at its start instead, so every replay draws new masks and the forward and backward of one replay the same
+	ones.  While the word holds 0 the masks are those of the seeds alone.  One word per device: a later instance replaces
+	an earlier one for new launches (launches already captured keep reading the word they were captured with, which
+	therefore lives as long as its owner).  The registered instance is kept alive by this module until close()."""
+
+	def __init__(self, device):
+		self.device = torch.device(device)
+		self.word = torch.zeros(1, dtype=torch.int32, device=self.device)
+		with torch.cuda.device(self.device):
+			L.check(L.load().vitk_dropout_epoch_set(self.word.data_ptr()))
+		_epoch_owner[self.device.index] = self
+
+	def advance(self):
+		L.check(L.load().vitk_dropout_epoch_advance(self.word.data_ptr(), L.stream()))
+
+	def set(self, value):
+		self.word.fill_(int(value))
+
+	def close(self):
+		if _epoch_owner.get(self.device.index) is self:
+			del _epoch_owner[self.device.index]
+			with torch.cuda.device(self.device):
+				L.check(L.load().vitk_dropout_epoch_set(None))
+
+
 def scale_by(t, g):
 	"""t * g for the scalar upstream gradient g (a 0-dim device tensor) of a loss."""
 	out = torch.empty_like(t)
