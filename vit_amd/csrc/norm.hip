@@ -260,20 +260,22 @@ __global__ __launch_bounds__(BWD_THREADS) void norm_bwd_kernel(const T* __restri
 }
 
 // dgamma[c] += sum over b of partials[b][c], dbeta[c] += sum over b of partials[b][d + c] (ncol = 2 * d; RMSNorm: ncol = d):
-// 32 columns x 8 row lanes per workgroup, the 8 partial sums of a column combined in LDS.  One writer per column.
-__global__ __launch_bounds__(256) void norm_bwd_reduce_kernel(const float* __restrict__ partials, int nblocks, int d, int ncol, float* dgamma, float* dbeta) {
-	__shared__ float sm[8][33];
+// 32 columns x 32 row lanes per workgroup (a row of 32 floats is one 128-byte line; at most 8 independent loads per
+// thread for 256 partial rows), the 32 partial sums of a column combined in LDS.  One writer per column.
+__global__ __launch_bounds__(1024) void norm_bwd_reduce_kernel(const float* __restrict__ partials, int nblocks, int d, int ncol, float* dgamma, float* dbeta) {
+	__shared__ float sm[32][33];
 	const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
 	const int c = blockIdx.x * 32 + cx;
 	float s = 0.f;
 	if (c < ncol) {
-		for (int b = ry; b < nblocks; b += 8) s += partials[(int64_t)b * 2 * d + c];
+#pragma unroll 8
+		for (int b = ry; b < nblocks; b += 32) s += partials[(int64_t)b * 2 * d + c];
 	}
 	sm[ry][cx] = s;
 	__syncthreads();
 	if (ry == 0 && c < ncol) {
 #pragma unroll
-		for (int r = 1; r < 8; ++r) s += sm[r][cx];
+		for (int r = 1; r < 32; ++r) s += sm[r][cx];
 		if (c < d) dgamma[c] += s;
 		else dbeta[c - d] += s;
 	}
@@ -425,7 +427,7 @@ int launch_bwd(const NormArgs& a, hipStream_t st) {
 	VITK_CHECK_LAUNCH();
 	if (partials != nullptr) {
 		const int ncol = RMS ? a.d : 2 * a.d;
-		hipLaunchKernelGGL(norm_bwd_reduce_kernel, dim3((unsigned)vitk_cdiv(ncol, 32)), dim3(256), 0, st, partials, grid, a.d, ncol, a.dgamma, a.dbeta);
+		hipLaunchKernelGGL(norm_bwd_reduce_kernel, dim3((unsigned)vitk_cdiv(ncol, 32)), dim3(1024), 0, st, partials, grid, a.d, ncol, a.dgamma, a.dbeta);
 		VITK_CHECK_LAUNCH();
 	}
 	return VITK_OK;
