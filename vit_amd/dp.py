@@ -73,11 +73,11 @@ class FlatModel:
 				p.grad = self.grad[o:o + p.numel()].view(p.shape)
 
 
-def broadcast_replica(flat, src=0, process_group=None):
+def broadcast_replica(flat, src=0, process_group=None, single_rank=False):
 	"""Every rank starts from rank `src`'s replica: ONE broadcast of the flat parameter buffer (the trainable parameters
 	are views into it), then the few tensors outside it (frozen parameters, BatchNorm statistics).  No-op in a single
-	process."""
-	if not (dist.is_initialized() and dist.get_world_size(process_group) > 1):
+	process (single_rank: run the collectives in a process group of one rank as well, see GradSync)."""
+	if not (dist.is_initialized() and (dist.get_world_size(process_group) > 1 or single_rank)):
 		return
 	dist.broadcast(flat.param, src=src, group=process_group)
 	inside = {id(p) for p in flat.params}
@@ -99,16 +99,19 @@ class GradSync:
 	unused parameters differ.  Inside no_sync() backward passes only accumulate (micro-batches); the reports of the
 	next backward outside it are counted."""
 
-	def __init__(self, flat, process_group=None):
+	def __init__(self, flat, process_group=None, single_rank=False):
+		"""single_rank: keep the whole machinery (hooks, bucket launches, waits) active in an initialised process group of
+		ONE rank, where every collective is the identity: the RCCL call sequence of a multi-GPU step, runnable on one GPU."""
 		self.flat = flat
 		self.group = process_group
 		self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+		self.active = self.world > 1 or (single_rank and dist.is_initialized())
 		self.expected = None  # reports per parameter in one backward, learnt from the first synchronised one
 		self.enabled = True
 		self.works = []
 		self.launched = []
 		self.hooks = [None] * len(flat.params)
-		if self.world > 1:
+		if self.active:
 			for i, p in enumerate(flat.params):
 				self.hooks[i] = self._make_hook(i)
 				p.register_post_accumulate_grad_hook(self.hooks[i])
@@ -171,7 +174,7 @@ class GradSync:
 		"""Wait for the collectives of this step (launching, in order, every bucket that has not gone out: the first
 		step's, and those holding parameters that received fewer gradient writes than expected, e.g. unused ones).
 		After this the flat gradient holds the SUM over ranks; the optimizer applies 1/world."""
-		if self.world > 1:
+		if self.active:
 			if self.late is not None:
 				name = self.flat.names[self.late]
 				self.reset()
@@ -337,10 +340,10 @@ class FlatAdamW(torch.optim.Optimizer):
 class Trainer:
 	"""zero_grad -> forward/backward (caller) -> step, with gradient sync when torch.distributed is initialised."""
 
-	def __init__(self, module, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, bucket_bytes=48 << 20):
+	def __init__(self, module, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, bucket_bytes=48 << 20, single_rank_sync=False):
 		self.flat = FlatModel(module, bucket_bytes)
-		broadcast_replica(self.flat)
-		self.sync = GradSync(self.flat)
+		broadcast_replica(self.flat, single_rank=single_rank_sync)
+		self.sync = GradSync(self.flat, single_rank=single_rank_sync)
 		self.opt = FlatAdamW(self.flat, lr, betas, eps, weight_decay)
 		# backward kernels that know about gradient sinks add straight into the flat gradient buffer (no temporary, no
 		# autograd accumulation kernel); they report through the same arrival hook as autograd's accumulation
@@ -383,7 +386,7 @@ class GraphedStep:
 	word stays registered on the device until close().  The returned tensors are overwritten by the next call."""
 
 	def __init__(self, trainer, loss_fn, example_inputs, warmup=3):
-		assert trainer.sync.world == 1, "graph capture of the step is single-process"
+		assert not trainer.sync.active, "graph capture of the step is single-process (the all-reduce hooks are not captured)"
 		assert ops.GEMM_PROFILE is None, "no per-launch event timing inside a captured step"
 		self.trainer, self.loss_fn = trainer, loss_fn
 		self.inputs = [t.clone() for t in example_inputs]
