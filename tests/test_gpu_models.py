@@ -470,7 +470,7 @@ def test_graphed_training_step_matches_eager(gpu):
 def test_graphed_step_draws_new_dropout_masks(gpu):
 	"""A captured step with dropout > 0: the seeds are fixed at capture, the device-side epoch word is advanced by the
 	graph itself, so replays on the same batch with frozen weights (lr 0) give different losses, while the same step
-	replayed from the same epoch gives the same loss bit for bit."""
+	replayed from the same epoch gives the same loss (up to the summation order of the batch mean's float atomics)."""
 	from vit_amd import dp, ops
 	c = dict(d_model=64, n_head=1, n_block=2, n_patch=4, d_ff=128, out_d=10, chw=(3, 16, 16), activation="gelu", norm="layernorm",
 		use_layer_scale=False)
@@ -491,9 +491,9 @@ def test_graphed_step_draws_new_dropout_masks(gpu):
 		losses = [float(g(x, y)) for _ in range(4)]
 		torch.cuda.synchronize()
 		assert int(g.epoch.word[0]) == 4
-		assert len(set(losses)) == 4, losses
+		assert min(abs(a - b) for i, a in enumerate(losses) for b in losses[i + 1:]) > 1e-4 * abs(losses[0]), losses
 		g.epoch.set(1)  # the second replay's epoch again
-		assert float(g(x, y)) == losses[1]
+		assert abs(float(g(x, y)) - losses[1]) < 1e-6 * abs(losses[1])
 	finally:
 		g.close()
 		trainer.close()
