@@ -287,7 +287,8 @@ def test_gemm_more_tiles_than_cus(gpu, act):
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("M,N,K", [(6400, 768, 512), (197 * 64, 768, 768), (197 * 32, 2304, 768), (6400 + 64, 256, 1024), (4099 * 8, 264, 320), (1000, 264, 192), (300, 130, 72), (197 * 8, 1000, 768),
 	(33280, 192, 576), (8000, 64, 192), (20000, 200, 136),  # these three: narrow layers over many rows (many K slices through scratch)
-	(33280, 192, 192), (33280, 768, 192), (33792, 192, 768), (65536, 64, 256), (16384, 384, 192), (4096, 128, 64), (8192, 320, 448)])  # the weight gradients of the 32 x 32 models (layer widths 64 ... 768 over 4 k ... 65 k tokens)
+	(33280, 192, 192), (33280, 768, 192), (33792, 192, 768), (65536, 64, 256), (16384, 384, 192), (4096, 128, 64), (8192, 320, 448),  # the weight gradients of the 32 x 32 models (layer widths 64 ... 768 over 4 k ... 65 k tokens)
+	(512, 10, 192), (256, 10, 384), (4100, 10, 64), (700, 3, 1000)])  # 10-class heads: one or a few output tiles of the float32-MFMA kernel, K (the batch) cut over workgroups
 def test_wgrad_with_bias_grad(gpu, dtype, M, N, K):
 	"""dw = dy^T x together with db = column sums of dy (what autograd's addmm backward produces), on every GEMM path:
 	large tiles with split-K (column sums fused into the kernel; whole-tile shapes on the deep-pipeline kernel, also with a
@@ -309,6 +310,23 @@ def test_wgrad_with_bias_grad(gpu, dtype, M, N, K):
 	ops.gemm(dy, x, c, N, K, M, N, K, K, a_layout=L.MN_MAJOR, b_layout=L.MN_MAJOR, accumulate=True, workspace=False)
 	ops.gemm(dy, x, c, N, K, M, N, K, K, a_layout=L.MN_MAJOR, b_layout=L.MN_MAJOR, accumulate=True)
 	assert relerr(c, 3.0 * (dyr.t() @ xr)) < tol
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,C,HW,P", [(3, 3, 32, 8), (2, 3, 224, 14), (5, 1, 48, 6), (2, 2, 12, 2), (1, 3, 30, 10)])
+def test_patchify_kernels(gpu, dtype, B, C, HW, P):
+	"""The patch gather and its inverse scatter (layers/embeddings.py:7-16), element-wise and 16-byte forms (patch edges
+	4, 16, 8, 6, 3): bit-exact against the oracle, and the scatter undoes the gather."""
+	from vit_amd import ops
+	import vit_amd._lib as L
+	x, _ = rnd((B, C, HW, HW), dtype, gpu, seed=21)
+	K = C * (HW // P) ** 2
+	patches = torch.empty((B * P * P, K), dtype=dtype, device=gpu)
+	L.check(L.load().vitk_patchify(L.ptr(x), L.ptr(patches), B, C, HW, P, L.dtype_code(dtype), L.stream()))
+	assert torch.equal(patches.cpu().reshape(B, P * P, K), O.patchify(x.cpu(), P))
+	back = torch.zeros_like(x)
+	L.check(L.load().vitk_unpatchify(L.ptr(patches), L.ptr(back), B, C, HW, P, L.dtype_code(dtype), L.stream()))
+	assert torch.equal(back.cpu(), x.cpu())
 
 
 @pytest.mark.parametrize("dtype", DTYPES)

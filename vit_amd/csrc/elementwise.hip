@@ -243,6 +243,30 @@ __global__ __launch_bounds__(256) void patchify_kernel(const T* __restrict__ src
 	}
 }
 
+// The same with V consecutive elements (16 bytes) of a pixel row per thread; needs p % V == 0 (a chunk stays inside one
+// pixel row of one patch) and 16-byte aligned buffers.  One index decomposition per chunk instead of one per element.
+template <typename T, int V, bool SCATTER>
+__global__ __launch_bounds__(256) void patchify_vec_kernel(const T* __restrict__ src, T* __restrict__ dst, int64_t B, int C, int HW, int P) {
+	const int p = HW / P;
+	const int64_t K = (int64_t)C * p * p;
+	const int64_t nchunk = B * P * P * K / V;
+	for (int64_t ch = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; ch < nchunk; ch += (int64_t)gridDim.x * blockDim.x) {
+		const int64_t i = ch * V;
+		const int64_t m = i / K;
+		const int k = (int)(i - m * K);
+		const int64_t b = m / (P * P);
+		const int t = (int)(m - b * P * P);
+		const int py = t / P, px = t - py * P;
+		const int c = k / (p * p), rem = k - c * p * p;
+		const int ii = rem / p, jj = rem - ii * p;
+		const int64_t img = ((b * C + c) * HW + (py * p + ii)) * HW + (px * p + jj);
+		if (SCATTER)
+			*reinterpret_cast<Pack<T, V>*>(dst + img) = *reinterpret_cast<const Pack<T, V>*>(src + i);
+		else
+			*reinterpret_cast<Pack<T, V>*>(dst + i) = *reinterpret_cast<const Pack<T, V>*>(src + img);
+	}
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void drop_cls_kernel(const T* __restrict__ x, T* __restrict__ out, int64_t B, int64_t tokens, int64_t d, int64_t lead) {
 	const int64_t per = (tokens - lead) * d;
@@ -650,8 +674,13 @@ extern "C" int vitk_patchify(const void* images, void* patches, int64_t B, int64
 	VITK_REQUIRE(images && patches, VITK_ERR_NULL);
 	VITK_REQUIRE(patch_args_ok(B, C, HW, n_patch), VITK_ERR_SHAPE);
 	DISPATCH_T(dtype, {
-		hipLaunchKernelGGL((patchify_kernel<T, false>), dim3(vitk_stream_grid(B * C * HW * HW, 256)), dim3(256), 0, (hipStream_t)stream, (const T*)images,
-			(T*)patches, B, (int)C, (int)HW, (int)n_patch);
+		constexpr int V = 16 / (int)sizeof(T);
+		if ((HW / n_patch) % V == 0 && vitk_aligned(images, 16) && vitk_aligned(patches, 16))
+			hipLaunchKernelGGL((patchify_vec_kernel<T, V, false>), dim3(vitk_stream_grid(B * C * HW * HW / V, 256)), dim3(256), 0, (hipStream_t)stream, (const T*)images,
+				(T*)patches, B, (int)C, (int)HW, (int)n_patch);
+		else
+			hipLaunchKernelGGL((patchify_kernel<T, false>), dim3(vitk_stream_grid(B * C * HW * HW, 256)), dim3(256), 0, (hipStream_t)stream, (const T*)images,
+				(T*)patches, B, (int)C, (int)HW, (int)n_patch);
 		VITK_CHECK_LAUNCH();
 		return VITK_OK;
 	});
@@ -661,8 +690,13 @@ extern "C" int vitk_unpatchify(const void* patches, void* images, int64_t B, int
 	VITK_REQUIRE(images && patches, VITK_ERR_NULL);
 	VITK_REQUIRE(patch_args_ok(B, C, HW, n_patch), VITK_ERR_SHAPE);
 	DISPATCH_T(dtype, {
-		hipLaunchKernelGGL((patchify_kernel<T, true>), dim3(vitk_stream_grid(B * C * HW * HW, 256)), dim3(256), 0, (hipStream_t)stream, (const T*)patches, (T*)images,
-			B, (int)C, (int)HW, (int)n_patch);
+		constexpr int V = 16 / (int)sizeof(T);
+		if ((HW / n_patch) % V == 0 && vitk_aligned(images, 16) && vitk_aligned(patches, 16))
+			hipLaunchKernelGGL((patchify_vec_kernel<T, V, true>), dim3(vitk_stream_grid(B * C * HW * HW / V, 256)), dim3(256), 0, (hipStream_t)stream, (const T*)patches,
+				(T*)images, B, (int)C, (int)HW, (int)n_patch);
+		else
+			hipLaunchKernelGGL((patchify_kernel<T, true>), dim3(vitk_stream_grid(B * C * HW * HW, 256)), dim3(256), 0, (hipStream_t)stream, (const T*)patches, (T*)images,
+				B, (int)C, (int)HW, (int)n_patch);
 		VITK_CHECK_LAUNCH();
 		return VITK_OK;
 	});
