@@ -184,3 +184,45 @@ def test_shared_module_microbatches_and_rank_dependent_unused_parameters():
 		assert shared_expected == 1 or shared_expected == 2  # autograd accumulates both uses before its hook fires once
 		assert early[0] == 0, "the first backward only learns the write counts"
 		assert n_buckets >= 4
+
+
+def _single_rank_worker(rank, world, port, ret):
+	sys.path.insert(0, ROOT)
+	os.environ["MASTER_ADDR"] = "127.0.0.1"
+	os.environ["MASTER_PORT"] = str(port)
+	dist.init_process_group("gloo", rank=rank, world_size=world)
+	from vit_amd import dp
+	torch.manual_seed(0)
+	model = nn.Sequential(nn.Linear(16, 32), nn.GELU(), nn.Linear(32, 4))
+	flat = dp.FlatModel(model, bucket_bytes=64)
+	idle = dp.GradSync(flat)  # one rank, default: nothing to do, no hooks
+	assert not idle.active and all(h is None for h in idle.hooks)
+	sync = dp.GradSync(flat, single_rank=True)
+	x = torch.randn(8, 16, generator=torch.Generator().manual_seed(1))
+	launched = []
+	for step in range(3):
+		flat.zero_grad()
+		model(x).square().sum().backward()
+		early = list(sync.launched)  # buckets that went out during backward (none in the first step: the counts are learnt there)
+		sync.finish()
+		launched.append(early)
+	ref = nn.Sequential(nn.Linear(16, 32), nn.GELU(), nn.Linear(32, 4))
+	ref.load_state_dict(model.state_dict())
+	ref(x).square().sum().backward()
+	same = all(torch.allclose(p.grad, q.grad, rtol=1e-6, atol=1e-7) for p, q in zip(model.parameters(), ref.parameters()))
+	ret[rank] = (same, len(flat.buckets), launched)
+	dist.destroy_process_group()
+
+
+def test_single_rank_group_runs_the_collective_sequence():
+	"""GradSync(single_rank=True) in a process group of ONE rank (what tools/rccl_single_rank.py runs over RCCL on one GPU):
+	hooks are installed, every bucket is all-reduced (the identity), in bucket order and from the second step on during
+	backward, and the gradients are those of a plain backward pass."""
+	port = 29500 + (os.getpid() % 1000) + 7
+	mgr = mp.Manager()
+	ret = mgr.dict()
+	mp.spawn(_single_rank_worker, args=(1, port, ret), nprocs=1, join=True)
+	same, n_buckets, launched = ret[0]
+	assert same and n_buckets >= 3
+	assert launched[0] == []  # first step: everything goes out in finish()
+	assert launched[1] == list(range(n_buckets)) and launched[2] == launched[1]
