@@ -217,6 +217,17 @@ int vitk_attention_bwd_noalloc(const void* dout, const void* q, const void* k, c
 	float scale, float dropout_p, uint64_t seed, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * A second stream for the weight-gradient GEMMs.  No counterpart in the reference (autograd runs nn.Linear's two
+ * backward products, layers/transformers.py:46-54 and layers/attention.py:28,47, one after the other on one stream).
+ * dW = dy^T x of a layer and its dx = dy W are independent: issued on a stream of the LOWEST priority the device offers,
+ * the weight-gradient workgroups take the CUs that the persistent input-gradient launch leaves idle in its partly filled
+ * last round of tiles, and never displace a workgroup of the caller's main stream that is ready to start.  The stream is
+ * created non-blocking (no implicit ordering against the null stream): the caller orders it with events.  low_priority
+ * = 0 creates a stream of default priority.  vitk_stream_destroy releases it (after the caller has synchronised it). */
+int vitk_stream_create(void** stream, int low_priority);
+int vitk_stream_destroy(void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Bandwidth-bound elementwise / reduction kernels.
  */
 /* dst[i] = (dst_dtype) src[i] */

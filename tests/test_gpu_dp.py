@@ -35,13 +35,19 @@ class _Done:
 		return True
 
 
+@pytest.mark.parametrize("second_stream", [False, True])
 @pytest.mark.parametrize("bucket_bytes", [1 << 30, 64 << 10, 4 << 10])
-def test_buckets_reduced_once_after_their_last_write(gpu, bucket_bytes, monkeypatch):
+def test_buckets_reduced_once_after_their_last_write(gpu, bucket_bytes, second_stream, monkeypatch):
+	"""second_stream: every weight-gradient GEMM of the fused blocks runs on the low-priority second stream (size threshold
+	off); a collective is ordered behind the stream that is current when it is launched, so the recorder waits for that
+	stream only and must still see every gradient write of its bucket."""
 	from vit_amd import dp, ops
 	records = []
+	monkeypatch.setattr(ops, "WGRAD_OVERLAP", second_stream)
+	monkeypatch.setattr(ops, "WGRAD_OVERLAP_MIN_FLOPS", 0.0)
 
 	def fake_all_reduce(t, op=None, group=None, async_op=False):
-		torch.cuda.synchronize()  # everything enqueued so far has landed: this is what the collective would read
+		torch.cuda.current_stream().synchronize()  # what is ordered before a collective launched here: this is what it would read
 		records.append((t.data_ptr(), t.numel(), t.detach().clone()))
 		t.mul_(2.0)  # "sum over two identical ranks"
 		return _Done()
@@ -63,7 +69,9 @@ def test_buckets_reduced_once_after_their_last_write(gpu, bucket_bytes, monkeypa
 		trainer.zero_grad()
 		with torch.autocast("cuda", dtype=torch.bfloat16):
 			loss = ops.cross_entropy(model(x), y)
+		sections = ops.wgrad_sections()
 		loss.backward()
+		assert (ops.wgrad_sections() > sections) == second_stream
 		during_backward = len(records)
 		arrivals = list(trainer.sync.arrivals)
 		trainer.sync.finish()
@@ -224,3 +232,73 @@ def test_trainer_steps_like_torch_adamw_with_the_reference_groups(gpu):
 	# the bf16 copy the next forward reads is the rounded float32 parameter
 	assert torch.equal(tr.opt.shadow, tr.flat.param.to(torch.bfloat16))
 	ops.clear_grad_sinks()
+
+
+def test_weight_gradients_on_the_second_stream_are_the_same_gradients(gpu):
+	"""The fused block's weight-gradient GEMMs issued on the low-priority second stream (behind the input-gradient launch
+	that shares their dy, joined at the end of backward) against the same step with everything on one stream: the kernels
+	and their summation orders are the same, so the gradients of the blocks' Linear layers must be identical bit for bit,
+	also when a second backward accumulates into them (the norm and patch-embedding gradients end in float atomics and
+	differ in the last bit from run to run on one stream already), and the optimizer step that follows must read complete
+	gradients."""
+	from vit_amd import dp, ops
+	ops.clear_grad_sinks()
+	g = torch.Generator().manual_seed(11)
+	x = torch.randn(32, 3, 16, 16, generator=g).to(gpu)
+	y = torch.randint(0, 10, (32,), generator=g).to(gpu)
+	saved = ops.WGRAD_OVERLAP, ops.WGRAD_OVERLAP_MIN_FLOPS
+	out = {}
+	try:
+		for mode in (False, True):
+			ops.WGRAD_OVERLAP, ops.WGRAD_OVERLAP_MIN_FLOPS = mode, 0.0
+			ops.clear_grad_sinks()
+			model = _model(gpu)
+			tr = dp.Trainer(model, lr=1e-2, weight_decay=0.05)
+			n0 = ops.wgrad_sections()
+			grads = []
+			for _ in range(2):
+				tr.zero_grad()
+				with torch.autocast("cuda", dtype=torch.bfloat16):
+					ops.cross_entropy(model(x), y).backward()
+					ops.cross_entropy(model(x.flip(0)), y).backward()  # accumulates
+				grads.append(tr.flat.grad.clone())  # (on the main stream: backward has joined the second stream)
+				tr.step()
+			assert (ops.wgrad_sections() - n0 == 2 * 2 * 4 * CFG["n_block"]) if mode else (ops.wgrad_sections() == n0)
+			out[mode] = (grads, tr.flat.param.clone())
+			spans = [(n, o, p.numel()) for n, o, p in zip(tr.flat.names, tr.flat.offsets, tr.flat.params)]
+			tr.close()
+	finally:
+		ops.WGRAD_OVERLAP, ops.WGRAD_OVERLAP_MIN_FLOPS = saved
+		ops.clear_grad_sinks()
+	exact = 0
+	for a, b in zip(out[False][0], out[True][0]):
+		for n, o, k in spans:
+			if n.startswith("blocks.") and "norm" not in n:
+				assert torch.equal(a[o:o + k], b[o:o + k]), n
+				exact += 1
+			else:
+				assert float((a[o:o + k] - b[o:o + k]).abs().max()) <= 1e-6 * float(a[o:o + k].abs().max()) + 1e-12, n
+	assert exact == 2 * 7 * CFG["n_block"]  # qkv, out (+bias), fc_in (+bias), fc_out (+bias) per block and step
+	assert float((out[False][1] - out[True][1]).abs().max()) < 1e-6
+
+
+def test_weight_gradient_on_the_second_stream_outside_backward(gpu):
+	"""ops.linear_wgrad(overlap=True) called outside a backward pass joins the second stream before it returns."""
+	from vit_amd import ops
+	saved = ops.WGRAD_OVERLAP, ops.WGRAD_OVERLAP_MIN_FLOPS
+	try:
+		ops.WGRAD_OVERLAP, ops.WGRAD_OVERLAP_MIN_FLOPS = True, 0.0
+		g = torch.Generator().manual_seed(2)
+		dy = torch.randn(4096, 256, generator=g).to(gpu).bfloat16()
+		xx = torch.randn(4096, 128, generator=g).to(gpu).bfloat16()
+		dw = torch.zeros(256, 128, device=gpu)
+		db = torch.zeros(256, device=gpu)
+		n0 = ops.wgrad_sections()
+		ops.linear_wgrad(dy, xx, bias_grad=True, dw_out=dw, db_out=db, overlap=True)
+		assert ops.wgrad_sections() == n0 + 1
+		got = dw.clone()  # main stream
+		want = dy.double().t() @ xx.double()
+		assert float((got.double() - want).abs().max() / want.abs().max()) < 1e-5
+		assert float((db.double() - dy.double().sum(0)).abs().max()) < 1e-2
+	finally:
+		ops.WGRAD_OVERLAP, ops.WGRAD_OVERLAP_MIN_FLOPS = saved

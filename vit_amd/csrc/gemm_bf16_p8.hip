@@ -510,6 +510,15 @@ int p8_blocks() {
 	return n;
 }
 
+bool p8_even_rounds() {
+	static int v = -1;
+	if (v < 0) {
+		const char* e = getenv("VITK_P8_EVEN_ROUNDS");
+		v = (e == nullptr || e[0] != '0') ? 1 : 0;
+	}
+	return v == 1;
+}
+
 template <int EPI, int ACT>
 int launch_p8(const P8Args& a, hipStream_t st) {
 	static bool attr = false;
@@ -520,7 +529,15 @@ int launch_p8(const P8Args& a, hipStream_t st) {
 	}
 	const int64_t tiles = (int64_t)a.tiles_m * a.tiles_n;
 	int blocks = p8_blocks();
-	if (tiles < blocks) blocks = (int)((tiles + 7) & ~7ll);
+	if (tiles < blocks) {
+		blocks = (int)((tiles + 7) & ~7ll);
+	} else if (p8_even_rounds()) {
+		// the fewest workgroups that still finish in the same number of rounds: 591 tiles take three rounds on 256 CUs and on 197,
+		// and the CUs left alone run whatever else is queued (weight gradients on their own stream, communication kernels)
+		// without delaying a workgroup of this launch
+		const int64_t rounds = vitk_cdiv(tiles, (int64_t)blocks);
+		blocks = (int)vitk_cdiv(tiles, rounds);
+	}
 	hipLaunchKernelGGL((gemm_bf16_p8_kernel<EPI, ACT>), dim3((unsigned)blocks), dim3(NTHREADS), LDS_BYTES, st, a);
 	VITK_CHECK_LAUNCH();
 	return VITK_OK;

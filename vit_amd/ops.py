@@ -5,7 +5,10 @@ weights keep the reference's nn.Linear layout [out_features, in_features].  `com
 dtype of the activations (float32 or bfloat16); weights are cast to it through a version-keyed
 cache, parameter gradients are produced in float32 and cast to the parameter dtype if needed.
 """
+import contextlib
+import ctypes
 import math
+import os
 import weakref
 
 import torch
@@ -206,7 +209,11 @@ def _sink(p):
 def _sink_done(p, sink):
 	"""Autograd's return value for a parameter whose gradient was accumulated into its sink."""
 	if sink[1] is not None:
-		sink[1](p)
+		lane = _wgrad_lanes.get(p.device.index) if p.is_cuda else None
+		if lane is not None and (lane.held or lane.hooked):
+			lane.run_behind(sink[1], p)  # (the callback may launch the bucket's all-reduce: behind the weight-gradient stream too)
+		else:
+			sink[1](p)
 	return None
 
 
@@ -249,17 +256,121 @@ def grad_as(g, like):
 DGRAD_TRANSPOSED_WEIGHTS = True  # see linear_dgrad
 DGRAD_T_MIN = 64  # smallest layer width that takes the transposed-copy path (ViT-Tiny, d = 192: +3.5 % on the step)
 GEMM_PROFILE = None  # set to a list to collect (kernel label, flops, start event, end event) per launch
+GEMM_PROFILE_SERIAL = False  # keep every GEMM on one stream (per-kernel timing without another kernel sharing the CUs)
 
 
-_workspaces = {}  # device index -> uint8 scratch tensor handed to vitk_gemm (K-split partial tiles)
+_workspaces = {}  # (device index, on the weight-gradient stream) -> uint8 scratch tensor handed to vitk_gemm (K-split partial tiles)
 
 
 def gemm_workspace(device):
-	ws = _workspaces.get(device.index)
+	key = (device.index, _on_wgrad_stream)
+	ws = _workspaces.get(key)
 	if ws is None:
 		ws = torch.empty(int(L.load().vitk_gemm_workspace_bytes()), dtype=torch.uint8, device=device)
-		_workspaces[device.index] = ws
+		_workspaces[key] = ws
 	return ws
+
+
+# --------------------------------------------------------------------------------------------------
+# weight gradients on a second stream
+# --------------------------------------------------------------------------------------------------
+# dW = dy^T x of a Linear and its dx = dy W are independent, and nothing reads dW before the optimizer step (or the
+# gradient all-reduce).  The persistent input-gradient GEMM of a 768-wide layer over 50 k tokens has 591 tiles for 256 CUs:
+# its third round keeps 79 CUs busy.  Weight-gradient GEMMs that add into gradient sinks are therefore issued on a stream
+# of the lowest priority: their workgroups (one tile x K slice each, not persistent) start wherever a CU is free and
+# fill those rounds, the tails of the attention kernels and the bandwidth-bound kernels in between.  The stream is joined
+# at the end of the backward pass (autograd's final callback), before anything can read a gradient.
+WGRAD_OVERLAP = os.environ.get("VITK_WGRAD_OVERLAP", "1") != "0"
+WGRAD_OVERLAP_MIN_FLOPS = 2e10  # smaller products stay on the main stream (the hand-over costs host time)
+_on_wgrad_stream = False  # launches made right now go to the weight-gradient stream (selects its own scratch buffer)
+_wgrad_lanes = {}  # device index -> _WgradLane
+
+
+class _WgradLane:
+	"""The weight-gradient stream of one device and what is in flight on it."""
+
+	sections = 0  # launches handed to a second stream so far (all devices)
+
+	def __init__(self, device):
+		h = ctypes.c_void_p()
+		L.check(L.load().vitk_stream_create(ctypes.byref(h), 1))
+		self.stream = torch.cuda.ExternalStream(h.value, device=device)
+		self.held = []  # operands of launches that may still run (the caching allocator must not hand them out again)
+		self.hooked = False  # the end-of-backward join is queued
+		self.last = None  # event behind the newest launch
+
+	@contextlib.contextmanager
+	def section(self, after, *operands):
+		"""Launches made inside go to the weight-gradient stream, ordered behind the event `after` (recorded on the main
+		stream where the operands were complete) or, without one, behind everything already queued on the current stream.
+		Inside a backward pass the join happens at its end; elsewhere, on leaving the section."""
+		global _on_wgrad_stream
+		if after is not None:
+			self.stream.wait_event(after)
+		else:
+			self.stream.wait_stream(torch.cuda.current_stream())
+		if not self.hooked:
+			try:
+				torch.autograd.Variable._execution_engine.queue_callback(self.join)
+				self.hooked = True
+			except RuntimeError:  # not inside a backward pass
+				pass
+		_on_wgrad_stream = True
+		_WgradLane.sections += 1
+		try:
+			with torch.cuda.stream(self.stream):
+				yield
+		finally:
+			_on_wgrad_stream = False
+		self.held.append(operands)
+		if not self.hooked:
+			self.join()
+
+	def join(self):
+		"""The current stream waits for everything issued on the weight-gradient stream so far."""
+		self.hooked = False
+		torch.cuda.current_stream().wait_stream(self.stream)
+		self.held.clear()
+
+	def run_behind(self, fn, *args):
+		"""fn(*args) with the weight-gradient stream current, ordered behind both streams: a collective that fn launches
+		starts after the gradients written on either."""
+		self.stream.wait_stream(torch.cuda.current_stream())
+		with torch.cuda.stream(self.stream):
+			fn(*args)
+
+
+def _wgrad_lane(t, flops):
+	"""The weight-gradient stream for a product of `flops` on t's device, or None if it should run on the current stream."""
+	if not WGRAD_OVERLAP or flops < WGRAD_OVERLAP_MIN_FLOPS or GEMM_PROFILE_SERIAL or torch.cuda.is_current_stream_capturing():
+		return None
+	lane = _wgrad_lanes.get(t.device.index)
+	if lane is None:
+		lane = _wgrad_lanes[t.device.index] = _WgradLane(t.device)
+	return lane
+
+
+def wgrad_mark(t):
+	"""An event on the current stream at this point (everything queued so far produces the operands of a weight-gradient
+	product that will be issued later, behind the launch of the input-gradient product that shares its dy), or None when
+	weight gradients stay on the main stream."""
+	if not WGRAD_OVERLAP or GEMM_PROFILE_SERIAL or not t.is_cuda or torch.cuda.is_current_stream_capturing():
+		return None
+	ev = torch.cuda.Event()
+	ev.record()
+	return ev
+
+
+def wgrad_sections():
+	"""How many weight-gradient products have been handed to a second stream so far (tests, diagnostics)."""
+	return _WgradLane.sections
+
+
+def join_wgrad_stream():
+	"""Make the current stream wait for weight-gradient launches still in flight (a no-op when there are none)."""
+	for lane in _wgrad_lanes.values():
+		if lane.held or lane.hooked:
+			lane.join()
 
 
 def gemm(A, B, C, M, N, K, lda, ldb, ldc, a_layout=L.K_MAJOR, b_layout=L.K_MAJOR, bias=None, epilogue=L.EPI_NONE, act=L.ACT_NONE,
@@ -351,11 +462,13 @@ def linear_dgrad(dy, w, act=L.ACT_NONE, pre=None, out=None, drop=()):
 	return dx
 
 
-def linear_wgrad(dy, x, bias_grad=False, dw_out=None, db_out=None):
+def linear_wgrad(dy, x, bias_grad=False, dw_out=None, db_out=None, overlap=False, after=None):
 	"""dw[N, K] = dy.T @ x in float32.  With bias_grad also db[N] = column sums of dy, formed by the same kernel from
 	the dy tiles it stages anyway (or by a column-sum kernel after it, where the GEMM path that runs does not fuse
 	it): returns (dw, db).  dw_out / db_out: float32 buffers that the results are ADDED into instead (gradient
-	sinks); they are returned in place of fresh tensors."""
+	sinks); they are returned in place of fresh tensors.  overlap: the caller writes neither dy nor x afterwards, so a
+	large product whose results go to sinks only may run on the weight-gradient stream (joined at the end of backward),
+	there ordered behind the event `after` (wgrad_mark) if given, else behind the current stream."""
 	M, N = dy.shape
 	K = x.shape[1]
 	assert x.shape[0] == M and dy.stride(1) == 1 and x.stride(1) == 1
@@ -363,7 +476,11 @@ def linear_wgrad(dy, x, bias_grad=False, dw_out=None, db_out=None):
 	db = None
 	if bias_grad:
 		db = db_out if db_out is not None else torch.zeros(N, dtype=torch.float32, device=dy.device)
-	gemm(dy, x, dw, N, K, M, dy.stride(0), x.stride(0), K, a_layout=L.MN_MAJOR, b_layout=L.MN_MAJOR, a_colsum=db, accumulate=dw_out is not None)
+	lane = None
+	if overlap and dw_out is not None and (db_out is not None or not bias_grad):
+		lane = _wgrad_lane(dy, 2.0 * M * N * K)
+	with (lane.section(after, dy, x) if lane is not None else contextlib.nullcontext()):
+		gemm(dy, x, dw, N, K, M, dy.stride(0), x.stride(0), K, a_layout=L.MN_MAJOR, b_layout=L.MN_MAJOR, a_colsum=db, accumulate=dw_out is not None)
 	return (dw, db) if bias_grad else dw
 
 
@@ -613,17 +730,22 @@ def _ffn_forward(x2, w1, b1, w2, b2, act, gated, residual=None, gamma=None, drop
 def _ffn_backward(dy2, x2, u, a, w1, w2, act, gated, need_dx=True, outs=(None, None, None, None), drop1=(0.0, 0)):
 	"""Returns (dx, dw1, db1, dw2, db2) with float32 parameter gradients.  outs = buffers to accumulate
 	(dw1, db1, dw2, db2) into (gradient sinks) or None each.  `a` is fc_out's input (after dropout1)."""
-	dw2, db2 = linear_wgrad(dy2, a, bias_grad=True, dw_out=outs[2], db_out=outs[3])
+	# each weight-gradient product is issued BEHIND the input-gradient product that shares its dy (the persistent kernel
+	# gets the CUs first, the weight gradient fills what its last round leaves idle) but depends only on the mark before it
+	ready = wgrad_mark(dy2)
 	if gated:
 		da = linear_dgrad(dy2, w2)
+		dw2, db2 = linear_wgrad(dy2, a, bias_grad=True, dw_out=outs[2], db_out=outs[3], overlap=True, after=ready)
 		if drop1[0] > 0.0:
 			dropout_add(da, None, drop1[0], drop1[1], out=da)
 		du = gated_act_bwd(da, u, w2.shape[1], act)
 	else:
 		# the dropout mask and the activation derivative are both elementwise factors of the same epilogue
 		du = linear_dgrad(dy2, w2, act=act, pre=u, drop=(drop1,))
-	dw1, db1 = linear_wgrad(du, x2, bias_grad=True, dw_out=outs[0], db_out=outs[1])
+		dw2, db2 = linear_wgrad(dy2, a, bias_grad=True, dw_out=outs[2], db_out=outs[3], overlap=True, after=ready)
+	ready = wgrad_mark(du)
 	dx = linear_dgrad(du, w1) if need_dx else None
+	dw1, db1 = linear_wgrad(du, x2, bias_grad=True, dw_out=outs[0], db_out=outs[1], overlap=True, after=ready)
 	return dx, dw1, db1, dw2, db2
 
 
@@ -669,12 +791,14 @@ def _mha_backward(dy2, x2, qkv, o, lse, wqkv, wo, B, S, n_head, need_dx=True, ou
 	"""Returns (dx, dwqkv, dwo, dbo).  outs = buffers to accumulate (dwqkv, dwo, dbo) into (gradient sinks) or None."""
 	d = x2.shape[1]
 	dh = d // n_head
-	dwo, dbo = linear_wgrad(dy2, o, bias_grad=True, dw_out=outs[1], db_out=outs[2])
+	ready = wgrad_mark(dy2)  # (weight gradients behind the input-gradient launches, as in _ffn_backward)
 	do = linear_dgrad(dy2, wo)
+	dwo, dbo = linear_wgrad(dy2, o, bias_grad=True, dw_out=outs[1], db_out=outs[2], overlap=True, after=ready)
 	dqkv = torch.empty_like(qkv)
 	attention_bwd(do, qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], o, lse, dqkv[:, :d], dqkv[:, d:2 * d], dqkv[:, 2 * d:], B, n_head, S, S, dh, drop=drop)
-	dwqkv = linear_wgrad(dqkv, x2, dw_out=outs[0])
+	ready = wgrad_mark(dqkv)
 	dx = linear_dgrad(dqkv, wqkv) if need_dx else None
+	dwqkv = linear_wgrad(dqkv, x2, dw_out=outs[0], overlap=True, after=ready)
 	return dx, dwqkv, dwo, dbo
 
 
