@@ -350,11 +350,11 @@ def _wgrad_lane(t, flops):
 	return lane
 
 
-def wgrad_mark(t):
-	"""An event on the current stream at this point (everything queued so far produces the operands of a weight-gradient
+def wgrad_mark(dy, x, dw_out):
+	"""An event on the current stream at this point (everything queued so far produces the operands dy, x of a weight-gradient
 	product that will be issued later, behind the launch of the input-gradient product that shares its dy), or None when
-	weight gradients stay on the main stream."""
-	if not WGRAD_OVERLAP or GEMM_PROFILE_SERIAL or not t.is_cuda or torch.cuda.is_current_stream_capturing():
+	that product will stay on the main stream (no gradient sink dw_out, too small, overlap off)."""
+	if dw_out is None or _wgrad_lane(dy, 2.0 * dy.shape[0] * dy.shape[1] * x.shape[1]) is None:
 		return None
 	ev = torch.cuda.Event()
 	ev.record()
@@ -732,7 +732,7 @@ def _ffn_backward(dy2, x2, u, a, w1, w2, act, gated, need_dx=True, outs=(None, N
 	(dw1, db1, dw2, db2) into (gradient sinks) or None each.  `a` is fc_out's input (after dropout1)."""
 	# each weight-gradient product is issued BEHIND the input-gradient product that shares its dy (the persistent kernel
 	# gets the CUs first, the weight gradient fills what its last round leaves idle) but depends only on the mark before it
-	ready = wgrad_mark(dy2)
+	ready = wgrad_mark(dy2, a, outs[2])
 	if gated:
 		da = linear_dgrad(dy2, w2)
 		dw2, db2 = linear_wgrad(dy2, a, bias_grad=True, dw_out=outs[2], db_out=outs[3], overlap=True, after=ready)
@@ -743,7 +743,7 @@ def _ffn_backward(dy2, x2, u, a, w1, w2, act, gated, need_dx=True, outs=(None, N
 		# the dropout mask and the activation derivative are both elementwise factors of the same epilogue
 		du = linear_dgrad(dy2, w2, act=act, pre=u, drop=(drop1,))
 		dw2, db2 = linear_wgrad(dy2, a, bias_grad=True, dw_out=outs[2], db_out=outs[3], overlap=True, after=ready)
-	ready = wgrad_mark(du)
+	ready = wgrad_mark(du, x2, outs[0])
 	dx = linear_dgrad(du, w1) if need_dx else None
 	dw1, db1 = linear_wgrad(du, x2, bias_grad=True, dw_out=outs[0], db_out=outs[1], overlap=True, after=ready)
 	return dx, dw1, db1, dw2, db2
@@ -791,12 +791,12 @@ def _mha_backward(dy2, x2, qkv, o, lse, wqkv, wo, B, S, n_head, need_dx=True, ou
 	"""Returns (dx, dwqkv, dwo, dbo).  outs = buffers to accumulate (dwqkv, dwo, dbo) into (gradient sinks) or None."""
 	d = x2.shape[1]
 	dh = d // n_head
-	ready = wgrad_mark(dy2)  # (weight gradients behind the input-gradient launches, as in _ffn_backward)
+	ready = wgrad_mark(dy2, o, outs[1])  # (weight gradients behind the input-gradient launches, as in _ffn_backward)
 	do = linear_dgrad(dy2, wo)
 	dwo, dbo = linear_wgrad(dy2, o, bias_grad=True, dw_out=outs[1], db_out=outs[2], overlap=True, after=ready)
 	dqkv = torch.empty_like(qkv)
 	attention_bwd(do, qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], o, lse, dqkv[:, :d], dqkv[:, d:2 * d], dqkv[:, 2 * d:], B, n_head, S, S, dh, drop=drop)
-	ready = wgrad_mark(dqkv)
+	ready = wgrad_mark(dqkv, x2, outs[0])
 	dx = linear_dgrad(dqkv, wqkv) if need_dx else None
 	dwqkv = linear_wgrad(dqkv, x2, dw_out=outs[0], overlap=True, after=ready)
 	return dx, dwqkv, dwo, dbo
