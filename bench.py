@@ -342,7 +342,7 @@ def main():
 			spath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r2_pmc_sq_counters.json")
 			if args.config == "vit_b16" and os.path.exists(spath):
 				for key, rec in json.load(open(spath)).items():
-					if key.startswith("whole training step"):
+					if key == "whole run" and isinstance(rec, dict) and "derived_mfma_pipe_busy_frac" in rec:
 						out["roofline"]["mfma_pipe_busy_frac_whole_step_pmc"] = round(rec["derived_mfma_pipe_busy_frac"], 4)
 						out["roofline"]["mfma_pipe_busy_source"] = "profiles/r2_pmc_sq_counters.json"
 		if not args.no_cpu_baseline and world == 1:
