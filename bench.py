@@ -151,6 +151,7 @@ def main():
 	ap.add_argument("--dropout", type=float, default=0.0, help="config.dropout (attention-probability, branch and feed-forward dropouts)")
 	ap.add_argument("--no-cpu-baseline", action="store_true")
 	ap.add_argument("--no-kernel-timing", action="store_true")
+	ap.add_argument("--no-pipelined-step", action="store_true", help="finish the optimizer step before the next forward starts (default: it runs under it, on the second stream)")
 	ap.add_argument("--lr", type=float, default=1e-4)
 	ap.add_argument("--launcher-selftest", action="store_true", help=argparse.SUPPRESS)
 	args = ap.parse_args()
@@ -207,7 +208,7 @@ def main():
 		teacher = frozen_teacher(20, c["out_d"], tsd).to(dev).to(memory_format=torch.channels_last)
 	else:
 		model = ViT(make_config(c, args.dropout)).to(dev)
-	trainer = dp.Trainer(model, lr=args.lr, weight_decay=0.05)
+	trainer = dp.Trainer(model, lr=args.lr, weight_decay=0.05, pipelined_step=not args.no_pipelined_step)
 	g = torch.Generator(device="cpu").manual_seed(1234 + rank)
 	x = torch.randn(batch, *c["chw"], generator=g).to(dev)
 	y = torch.randint(0, c["out_d"], (batch,), generator=g).to(dev)

@@ -346,6 +346,15 @@ int vitk_adamw_device_step(float* p, const float* g, float* m, float* v, const u
  * HIP graph then follows the schedule on replay. */
 int vitk_adamw_device_hparams(float* p, const float* g, float* m, float* v, const uint8_t* wd_mask, void* p_bf16, int64_t n,
 	const float* hparams, int64_t* step_state, float grad_scale, void* stream);
+/* The step of vitk_adamw_device_hparams in pieces, for a caller that pipelines the optimizer under the next forward pass
+ * (no counterpart in the reference, whose optimizer.step() in train.py:55 finishes before the next batch starts):
+ * vitk_adamw_advance increments the device-side step count once and derives the bias corrections; vitk_adamw_range then
+ * updates ANY sub-range of the flat buffers (pointers already offset, n elements) with the corrections and
+ * hyper-parameters found in device memory, and with zero_grad != 0 also clears the gradients it has consumed (the
+ * optimizer.zero_grad() of train.py:45).  The ranges of one step may run on any stream behind the advance. */
+int vitk_adamw_advance(int64_t* step_state, const float* hparams, void* stream);
+int vitk_adamw_range(float* p, float* g, float* m, float* v, const uint8_t* wd_mask, void* p_bf16, int64_t n,
+	const float* hparams, const int64_t* step_state, float grad_scale, int zero_grad, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * CvT pieces.

@@ -302,3 +302,52 @@ def test_weight_gradient_on_the_second_stream_outside_backward(gpu):
 		assert float((db.double() - dy.double().sum(0)).abs().max()) < 1e-2
 	finally:
 		ops.WGRAD_OVERLAP, ops.WGRAD_OVERLAP_MIN_FLOPS = saved
+
+
+def test_pipelined_optimizer_step_is_the_same_training_run(gpu):
+	"""dp.Trainer(pipelined_step=True): the optimizer runs piece by piece on the second stream while the next forward has
+	already started; every kernel that reads a parameter waits for its piece, the step clears the gradients it consumed.
+	Same kernels on the same numbers as the plain step: parameters, moments and the bf16 / transposed copies after five
+	steps agree to the run-to-run noise of the norm gradients' float atomics, and a checkpoint taken in between sees the
+	finished step."""
+	from vit_amd import dp, ops
+	g = torch.Generator().manual_seed(5)
+	xs = [torch.randn(16, 3, 16, 16, generator=g).to(gpu) for _ in range(5)]
+	ys = [torch.randint(0, 10, (16,), generator=g).to(gpu) for _ in range(5)]
+	out = {}
+	for mode in (False, True):
+		ops.clear_grad_sinks()
+		model = _model(gpu)
+		tr = dp.Trainer(model, lr=3e-3, weight_decay=0.05, pipelined_step=mode)
+		assert len(tr.opt.pieces) == 3 + CFG["n_block"] + 2 - 1 or len(tr.opt.pieces) >= CFG["n_block"] + 2
+		losses = []
+		for i, (x, y) in enumerate(zip(xs, ys)):
+			tr.zero_grad()
+			with torch.autocast("cuda", dtype=torch.bfloat16):
+				loss = ops.cross_entropy(model(x), y)
+			loss.backward()
+			tr.step()
+			losses.append(loss.detach())
+			if i == 2:
+				sd = tr.opt.state_dict()  # waits for the step by itself
+				assert int(tr.opt.step_state[0]) == 3
+				assert all(float(st["step"]) == 3.0 for st in sd["state"].values())
+		if mode:
+			assert tr.opt.grads_cleared
+		tr.wait_step()
+		if mode:
+			assert float(tr.flat.grad.abs().max()) == 0.0  # consumed and cleared
+		two_d = torch.zeros(tr.flat.numel, dtype=torch.bool, device=gpu)  # (the transposed copies exist for the matrices only)
+		for p_, o in zip(tr.flat.params, tr.flat.offsets):
+			if p_.dim() == 2:
+				two_d[o:o + p_.numel()] = True
+		out[mode] = (tr.flat.param.clone(), tr.opt.m.clone(), tr.opt.v.clone(), tr.opt.shadow.clone(), tr.opt.shadow_t[two_d].clone(), torch.stack(losses).cpu())
+		assert torch.equal(tr.opt.shadow, tr.flat.param.to(torch.bfloat16))
+		tr.close()
+	ops.clear_grad_sinks()
+	a, b = out[False], out[True]
+	assert float((a[5] - b[5]).abs().max()) < 1e-3, (a[5], b[5])
+	for i in range(3):
+		assert float((a[i] - b[i]).abs().max()) <= 1e-5 * float(a[i].abs().max()), i
+	assert float((a[3].float() - b[3].float()).abs().max()) <= 1e-2 * float(a[3].float().abs().max())
+	assert float((a[4].float() - b[4].float()).abs().max()) <= 1e-2 * float(a[4].float().abs().max())

@@ -92,6 +92,8 @@ SIGNATURES = {
 	"vitk_adamw": [P, P, P, P, P, P, I64, FL, FL, FL, FL, FL, I64, FL, P],
 	"vitk_adamw_device_step": [P, P, P, P, P, P, I64, FL, FL, FL, FL, FL, P, FL, P],
 	"vitk_adamw_device_hparams": [P, P, P, P, P, P, I64, P, P, FL, P],
+	"vitk_adamw_advance": [P, P, P],
+	"vitk_adamw_range": [P, P, P, P, P, P, I64, P, P, FL, I, P],
 	"vitk_dwconv_fwd": [P, P, P, I64, I64, I64, I64, I64, I64, I64, I, P],
 	"vitk_dwconv_bwd": [P, P, P, P, P, I64, I64, I64, I64, I64, I64, I64, I, P],
 	"vitk_im2col": [P, P, I64, I64, I64, I64, I64, I64, I64, I64, I, I, P],

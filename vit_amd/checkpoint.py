@@ -24,6 +24,7 @@ def _group_order(flat, decay_filter=no_decay):
 
 def optimizer_state_dict(opt, decay_filter=no_decay):
 	"""`torch.optim.AdamW.state_dict()` of the fused optimizer `opt` (dp.FlatAdamW).  Moments are copies."""
+	opt.wait_pipelined()  # (a pipelined step may still be writing the buffers)
 	flat = opt.flat
 	dec, nod = _group_order(flat, decay_filter)
 	state = {}
@@ -54,6 +55,7 @@ def optimizer_state_dict(opt, decay_filter=no_decay):
 def load_optimizer_state_dict(opt, sd, decay_filter=no_decay):
 	"""Fill the fused optimizer's moments, step count and hyper-parameters from a `torch.optim.AdamW.state_dict()`
 	whose groups follow the reference's rule.  Raises ValueError when group sizes or tensor shapes do not fit."""
+	opt.wait_pipelined()  # (a pipelined step may still be writing the buffers)
 	flat = opt.flat
 	dec, nod = _group_order(flat, decay_filter)
 	groups = sd["param_groups"]
@@ -91,6 +93,8 @@ def load_optimizer_state_dict(opt, sd, decay_filter=no_decay):
 def load_model_state_dict(trainer_or_none, module, sd, strict=True):
 	"""`module.load_state_dict(sd)` that keeps the parameters inside the trainer's flat buffer (load_state_dict copies in
 	place) and then refreshes the bfloat16 / transposed copies the kernels read."""
+	if trainer_or_none is not None:
+		trainer_or_none.wait_step()
 	out = module.load_state_dict(sd, strict=strict)
 	if trainer_or_none is not None:
 		trainer_or_none.opt.refresh_copies()
@@ -99,6 +103,7 @@ def load_model_state_dict(trainer_or_none, module, sd, strict=True):
 
 def save_checkpoint(path, module, trainer, epoch, best_val_loss=float("inf"), scheduler=None, config=None, args=None, best=False):
 	"""train.py:121-145 there, field for field (including the `_best.pt` side file and the `epoch + 1` convention)."""
+	trainer.wait_step()  # (module.state_dict() below reads the parameters)
 	ck = {
 		"epoch": epoch + 1,
 		"model_state_dict": {k: v.detach().clone() for k, v in module.state_dict().items()},

@@ -409,9 +409,9 @@ __global__ void adamw_advance_kernel(int64_t* step_state, float b1, float b2, co
 	corr[1] = (float)(1.0 / sqrt(1.0 - pow((double)b2, (double)st)));
 }
 
-__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* g, float* __restrict__ m, float* __restrict__ v,
 	const uint8_t* __restrict__ wd_mask, bf16_t* __restrict__ p16, int64_t n, float lr, float b1, float b2, float eps, float wd, float inv_bc1,
-	float inv_sqrt_bc2, float gscale, const int64_t* __restrict__ step_state, const float* __restrict__ hp) {
+	float inv_sqrt_bc2, float gscale, const int64_t* __restrict__ step_state, const float* __restrict__ hp, float* g_clear = nullptr) {
 	if (step_state != nullptr) {
 		const float* corr = reinterpret_cast<const float*>(step_state + 1);
 		inv_bc1 = corr[0];
@@ -442,6 +442,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
 		m[i] = mv;
 		v[i] = vv;
 		if (p16) p16[i] = (bf16_t)pv;
+		if (g_clear) g_clear[i] = 0.f;  // (g_clear == g: the gradient is consumed)
 	}
 }
 
@@ -817,6 +818,25 @@ extern "C" int vitk_adamw_device_hparams(float* p, const float* g, float* m, flo
 	VITK_CHECK_LAUNCH();
 	hipLaunchKernelGGL(adamw_kernel, dim3(vitk_stream_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, wd_mask, (bf16_t*)p_bf16, n, 0.f, 0.f, 0.f, 0.f, 0.f,
 		1.f, 1.f, grad_scale, (const int64_t*)step_state, hparams);
+	VITK_CHECK_LAUNCH();
+	return VITK_OK;
+}
+
+extern "C" int vitk_adamw_advance(int64_t* step_state, const float* hparams, void* stream) {
+	VITK_REQUIRE(step_state && hparams, VITK_ERR_NULL);
+	VITK_REQUIRE(vitk_aligned(hparams, 4), VITK_ERR_ALIGN);
+	hipLaunchKernelGGL(adamw_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step_state, 0.f, 0.f, hparams);
+	VITK_CHECK_LAUNCH();
+	return VITK_OK;
+}
+
+extern "C" int vitk_adamw_range(float* p, float* g, float* m, float* v, const uint8_t* wd_mask, void* p_bf16, int64_t n, const float* hparams,
+	const int64_t* step_state, float grad_scale, int zero_grad, void* stream) {
+	VITK_REQUIRE(p && g && m && v && step_state && hparams, VITK_ERR_NULL);
+	VITK_REQUIRE(n > 0, VITK_ERR_SHAPE);
+	VITK_REQUIRE(vitk_aligned(hparams, 4), VITK_ERR_ALIGN);
+	hipLaunchKernelGGL(adamw_kernel, dim3(vitk_stream_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, p, (const float*)g, m, v, wd_mask, (bf16_t*)p_bf16, n, 0.f, 0.f, 0.f, 0.f,
+		0.f, 1.f, 1.f, grad_scale, step_state, hparams, zero_grad ? g : (float*)nullptr);
 	VITK_CHECK_LAUNCH();
 	return VITK_OK;
 }

@@ -65,8 +65,9 @@ class FlatModel:
 			for i in idxs:
 				self.bucket_of[i] = b
 
-	def zero_grad(self):
-		self.grad.zero_()
+	def zero_grad(self, fill=True):
+		if fill:
+			self.grad.zero_()
 		# autograd replaces .grad when it is None; keep the views attached
 		for p, o in zip(self.params, self.offsets):
 			if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * o:
@@ -231,7 +232,8 @@ class FlatAdamW(torch.optim.Optimizer):
 			# transposed bf16 copies of the 2-D weights (the input-gradient GEMMs read them), refreshed by ONE launch per step
 			self.shadow_t = torch.empty(flat.numel, dtype=torch.bfloat16, device=dev)
 			items, tiles = [], []
-			for p, o in zip(flat.params, flat.offsets):
+			self._tile_range = {}  # parameter index -> [first, end) in the tile list of the batched transpose
+			for pi, (p, o) in enumerate(zip(flat.params, flat.offsets)):
 				if p.dim() >= 2:
 					sh = self.shadow[o:o + p.numel()].view(p.shape)
 					ops.register_shadow(p, sh, self.refresh_copies)
@@ -240,14 +242,35 @@ class FlatAdamW(torch.optim.Optimizer):
 						rows, cols = p.shape
 						sht = self.shadow_t[o:o + p.numel()].view(cols, rows)
 						ops.register_transposed(sh, sht)
+						first_tile = len(tiles)
 						for tr in range((rows + 63) // 64):
 							for tc in range((cols + 63) // 64):
 								tiles.append((len(items), tr, tc, 0))
 						items.append((sh.data_ptr(), sht.data_ptr(), rows, cols))
+						self._tile_range[pi] = (first_tile, len(tiles))
 			self.t_items = torch.tensor(items, dtype=torch.int64).reshape(-1, 4).to(dev)  # vitk_transpose_item: 2 pointers + 2 int64
 			self.t_tiles = torch.tensor(tiles, dtype=torch.int32).reshape(-1, 4).to(dev)
 			self._refresh_transposed()
 		self.sync_hparams()
+		# pieces of the flat buffers for the pipelined step: one per top-level child of the module (per transformer block
+		# inside a ModuleList), in buffer order = the order a forward pass first reads them
+		self.pieces = []  # [start, end, first tile, end tile, parameter indices]
+		key_of = lambda n: ".".join(n.split(".")[:2]) if n.split(".")[0] in ("blocks", "layers", "stages") else n.split(".")[0]
+		prev = None
+		for pi, (n, p, o) in enumerate(zip(flat.names, flat.params, flat.offsets)):
+			k = key_of(n)
+			if k != prev:
+				self.pieces.append([o, o, None, None, []])
+				prev = k
+			pc = self.pieces[-1]
+			pc[1] = o + (p.numel() + 63) // 64 * 64
+			pc[4].append(pi)
+			tr = getattr(self, "_tile_range", {}).get(pi)
+			if tr is not None:
+				pc[2] = tr[0] if pc[2] is None else pc[2]
+				pc[3] = tr[1]
+		assert self.pieces[0][0] == 0 and self.pieces[-1][1] == flat.numel and all(a[1] == b[0] for a, b in zip(self.pieces, self.pieces[1:]))
+		self.grads_cleared = False  # the last step cleared the gradients it consumed (pipelined step)
 
 	# the first group's hyper-parameters under the names the fused optimizer had before it grew parameter groups
 	def _g0(self):
@@ -291,6 +314,7 @@ class FlatAdamW(torch.optim.Optimizer):
 	def refresh_copies(self):
 		"""Re-derive the bfloat16 and transposed copies after the float32 parameters were written from outside
 		(load_state_dict, a broadcast).  weight_as() calls this by itself when a parameter's version counter moved."""
+		self.wait_pipelined()
 		if self.shadow is not None:
 			L.check(L.load().vitk_cast(L.ptr(self.flat.param), L.ptr(self.shadow), self.flat.numel, L.F32, L.BF16, L.stream()))
 			self._refresh_transposed()
@@ -301,6 +325,7 @@ class FlatAdamW(torch.optim.Optimizer):
 
 	def close(self):
 		"""Withdraw the copies registered with ops (they would otherwise outlive this optimizer with stale contents)."""
+		self.wait_pipelined()
 		for p, sh in self._registered:
 			ops.unregister_shadow(p)
 			ops.unregister_transposed(sh)
@@ -308,11 +333,13 @@ class FlatAdamW(torch.optim.Optimizer):
 
 	def set_step(self, n):
 		"""Set the number of steps taken so far (resuming from a checkpoint)."""
+		self.wait_pipelined()
 		self.step_count = int(n)
 		self.step_state.fill_(int(n))
 
 	def zero_grad(self, set_to_none=False):
-		self.flat.zero_grad()  # the gradients stay views of the flat buffer
+		self.flat.zero_grad(fill=not self.grads_cleared)  # the gradients stay views of the flat buffer
+		self.grads_cleared = False
 
 	def state_dict(self):
 		from . import checkpoint
@@ -322,13 +349,21 @@ class FlatAdamW(torch.optim.Optimizer):
 		from . import checkpoint
 		checkpoint.load_optimizer_state_dict(self, sd)
 
-	def step(self, closure=None, grad_scale=1.0):
+	def step(self, closure=None, grad_scale=1.0, pipelined=False):
+		"""pipelined: issue the step on the low-priority second stream, piece by piece in the order the next forward pass
+		reads the parameters, clearing each gradient as it is consumed (no zero_grad pass), and return at once: every
+		kernel of this package that reads a parameter first makes its stream wait for that parameter's piece
+		(ops.weight_as), so the next forward starts while the later blocks are still being updated, and the update runs
+		on the CUs its GEMMs leave idle.  Anything ELSE that reads parameters, moments or gradients (a checkpoint, a
+		comparison in a test, .cpu()) must call wait_pipelined() first.  Ignored under HIP graph capture."""
 		# the step count that the bias corrections use lives in device memory (self.step_state) and is advanced by the
 		# launch itself, so the same launch can be replayed from a captured HIP graph; step_count mirrors it on the host
 		assert closure is None, "the fused step takes no closure"
 		self.step_count += 1
 		self.sync_hparams()
 		f = self.flat
+		if pipelined and self.shadow is not None and f.param.is_cuda and not torch.cuda.is_current_stream_capturing():
+			return self._step_pipelined(grad_scale)
 		L.check(L.load().vitk_adamw_device_hparams(L.ptr(f.param), L.ptr(f.grad), L.ptr(self.m), L.ptr(self.v), L.ptr(self.wd_mask), L.ptr(self.shadow), f.numel,
 			L.ptr(self.hparams), L.ptr(self.step_state), grad_scale, L.stream()))
 		if self.shadow is None:
@@ -337,10 +372,38 @@ class FlatAdamW(torch.optim.Optimizer):
 		ops.weights_changed()  # transposed copies cached by ops itself (weights without a kept copy) are stale now
 
 
+	def _step_pipelined(self, grad_scale):
+		f, lib = self.flat, L.load()
+		lane = ops.second_stream(f.param.device)
+		lane.stream.wait_stream(torch.cuda.current_stream())  # the gradients are complete (backward has joined, collectives were waited for)
+		pending = []
+		with torch.cuda.stream(lane.stream):
+			L.check(lib.vitk_adamw_advance(L.ptr(self.step_state), L.ptr(self.hparams), L.stream()))
+			for start, end, t0, t1, idxs in self.pieces:
+				off = lambda t, esz: t.data_ptr() + start * esz
+				L.check(lib.vitk_adamw_range(off(f.param, 4), off(f.grad, 4), off(self.m, 4), off(self.v, 4), off(self.wd_mask, 1), off(self.shadow, 2), end - start,
+					L.ptr(self.hparams), L.ptr(self.step_state), grad_scale, 1, L.stream()))
+				if t0 is not None and t1 > t0:
+					L.check(lib.vitk_transpose_batched(L.ptr(self.t_items), self.t_tiles.data_ptr() + 16 * t0, t1 - t0, L.BF16, L.stream()))
+				ev = torch.cuda.Event()
+				ev.record()
+				pending.append((ev, [f.params[i] for i in idxs]))
+		ops.set_pending_weights(pending, lane)
+		self.grads_cleared = True
+		ops.weights_changed()
+
+	def wait_pipelined(self):
+		"""The current stream waits for a pipelined step still in flight (a no-op otherwise)."""
+		ops.wait_pending_weights()
+
+
 class Trainer:
 	"""zero_grad -> forward/backward (caller) -> step, with gradient sync when torch.distributed is initialised."""
 
-	def __init__(self, module, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, bucket_bytes=48 << 20, single_rank_sync=False):
+	def __init__(self, module, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, bucket_bytes=48 << 20, single_rank_sync=False, pipelined_step=False):
+		"""pipelined_step: step() returns while the optimizer still runs on the second stream (FlatAdamW.step); the next
+		forward / backward of this package synchronise with it by themselves, other readers call wait_step() first."""
+		self.pipelined_step = pipelined_step
 		self.flat = FlatModel(module, bucket_bytes)
 		broadcast_replica(self.flat, single_rank=single_rank_sync)
 		self.sync = GradSync(self.flat, single_rank=single_rank_sync)
@@ -351,7 +414,15 @@ class Trainer:
 			ops.register_grad_sink(p, self.flat.grad[o:o + p.numel()].view(p.shape), self.sync.hooks[i])
 
 	def zero_grad(self):
-		self.flat.zero_grad()
+		if self.opt.grads_cleared:  # the pipelined step cleared every gradient as it consumed it
+			self.opt.grads_cleared = False
+			self.flat.zero_grad(fill=False)
+		else:
+			self.flat.zero_grad()
+
+	def wait_step(self):
+		"""The current stream waits for a pipelined optimizer step still in flight."""
+		self.opt.wait_pipelined()
 
 	def no_sync(self):
 		"""Gradient accumulation: `with trainer.no_sync(): loss.backward()` for all micro-batches but the last."""
@@ -359,7 +430,7 @@ class Trainer:
 
 	def step(self):
 		self.sync.finish()
-		self.opt.step(grad_scale=1.0 / self.sync.world)
+		self.opt.step(grad_scale=1.0 / self.sync.world, pipelined=self.pipelined_step)
 
 	def close(self):
 		"""Withdraw everything this trainer registered with ops (bf16 / transposed weight copies, gradient sinks)."""
@@ -387,6 +458,7 @@ class GraphedStep:
 
 	def __init__(self, trainer, loss_fn, example_inputs, warmup=3):
 		assert not trainer.sync.active, "graph capture of the step is single-process (the all-reduce hooks are not captured)"
+		trainer.wait_step()
 		assert ops.GEMM_PROFILE is None, "no per-launch event timing inside a captured step"
 		self.trainer, self.loss_fn = trainer, loss_fn
 		self.inputs = [t.clone() for t in example_inputs]

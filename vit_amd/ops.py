@@ -78,9 +78,47 @@ def invalidate_casts():
 	_wt_cache.clear()
 
 
+# Parameters that a pipelined optimizer step (dp.FlatAdamW.step(pipelined=True)) is still updating on the second stream:
+# id(param) -> [event behind the update of its piece, waited for already].  weight_as() is the one door through which the
+# kernels of this package reach a parameter (its float32 master, its bf16 copy, the transposed copy behind that), so the
+# wait lives there; one wait per piece (a marker packet on the stream costs a few microseconds).
+_pending_weights = {}
+_pending_lane = None
+
+
+def set_pending_weights(pieces, lane):
+	"""pieces: [(event, [parameters])] of a step just issued on `lane`."""
+	global _pending_lane
+	for k in [k for k, rec in _pending_weights.items() if rec[1]]:  # (waited for already; records of another optimizer stay)
+		del _pending_weights[k]
+	for ev, params in pieces:
+		rec = [ev, False]
+		for p in params:
+			_pending_weights[id(p)] = rec
+	_pending_lane = lane
+
+
+def wait_pending_weights():
+	"""The current stream waits for the whole pipelined step in flight, if any."""
+	global _pending_lane
+	if _pending_lane is not None:
+		torch.cuda.current_stream().wait_stream(_pending_lane.stream)
+		_pending_lane = None
+	_pending_weights.clear()
+
+
+def _await_weight(w):
+	if _pending_weights:
+		rec = _pending_weights.get(id(w))
+		if rec is not None and not rec[1]:
+			torch.cuda.current_stream().wait_event(rec[0])
+			rec[1] = True
+
+
 def weight_as(w, dtype):
 	"""`w` in the compute dtype.  The cast of a parameter is cached until the parameter is modified
 	in place (optimizer step, load_state_dict), which bumps its version counter."""
+	_await_weight(w)
 	if w.dtype == dtype and w.is_contiguous():
 		return w.detach()
 	if dtype == torch.bfloat16:
@@ -107,6 +145,7 @@ def weight_padded(w, dtype, rows, cols, ld):
 	kernel, cached until the parameter is modified in place."""
 	if ld == cols:
 		return weight_as(w, dtype).reshape(rows, cols)
+	_await_weight(w)
 	key = (w._version, dtype, w.data_ptr(), ld)
 	hit = _cast_cache.get((id(w), "pad"))
 	if hit is not None and hit[0]() is w and hit[1] == key:
@@ -359,6 +398,14 @@ def wgrad_mark(dy, x, dw_out):
 	ev = torch.cuda.Event()
 	ev.record()
 	return ev
+
+
+def second_stream(device):
+	"""The low-priority second stream of `device` (created on first use)."""
+	lane = _wgrad_lanes.get(device.index)
+	if lane is None:
+		lane = _wgrad_lanes[device.index] = _WgradLane(device)
+	return lane
 
 
 def wgrad_sections():
