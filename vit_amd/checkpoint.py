@@ -94,7 +94,7 @@ def load_model_state_dict(trainer_or_none, module, sd, strict=True):
 	"""`module.load_state_dict(sd)` that keeps the parameters inside the trainer's flat buffer (load_state_dict copies in
 	place) and then refreshes the bfloat16 / transposed copies the kernels read."""
 	if trainer_or_none is not None:
-		trainer_or_none.wait_step()
+		trainer_or_none.opt.wait_pipelined()
 	out = module.load_state_dict(sd, strict=strict)
 	if trainer_or_none is not None:
 		trainer_or_none.opt.refresh_copies()
@@ -103,7 +103,7 @@ def load_model_state_dict(trainer_or_none, module, sd, strict=True):
 
 def save_checkpoint(path, module, trainer, epoch, best_val_loss=float("inf"), scheduler=None, config=None, args=None, best=False):
 	"""train.py:121-145 there, field for field (including the `_best.pt` side file and the `epoch + 1` convention)."""
-	trainer.wait_step()  # (module.state_dict() below reads the parameters)
+	trainer.opt.wait_pipelined()  # (module.state_dict() below reads the parameters)
 	ck = {
 		"epoch": epoch + 1,
 		"model_state_dict": {k: v.detach().clone() for k, v in module.state_dict().items()},
