@@ -129,6 +129,13 @@ typedef struct vitk_gemm_desc {
 int vitk_gemm(const vitk_gemm_desc* desc, void* stream);
 /* Size of `workspace` that is enough for any problem on this device (a fixed number of 256x256 float32 tiles). */
 int64_t vitk_gemm_workspace_bytes(void);
+/* on != 0: the persistent GEMM kernels launch the FEWEST workgroups that finish a problem in the same number of rounds of
+ * tiles (591 tiles: 197 workgroups x 3 instead of 256 of which 79 walk a third tile), so that the remaining CUs stay free
+ * for kernels of other streams for the whole launch -- the communication kernels of a gradient all-reduce that overlaps the
+ * backward pass (no counterpart in the reference, which has no distributed path).  Costs 0.2 ms of a 34 ms ViT-B/16 step
+ * when nothing else runs, saves 4 % of it when another kernel holds 16 CUs half of the time.  Process-wide; returns the
+ * previous setting.  Default off. */
+int vitk_gemm_leave_cus_free(int on);
 /* 1 if vitk_gemm would run this problem on the bf16 MFMA kernel, 0 if on the generic float32-MFMA kernel. */
 int vitk_gemm_uses_bf16_mfma(const vitk_gemm_desc* desc);
 /* Name of the kernel family the calling thread's last vitk_gemm launched ("gemm_bf16_p8_kernel", "gemm_bf16_p8w_kernel",

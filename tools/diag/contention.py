@@ -81,5 +81,5 @@ th.join()
 side.synchronize()
 again = timed()
 ideal = alone * (1 + duty * n_wg / 256.0)
-print(f"{os.environ.get('VITK_P8_STATIC', '0')=}: alone {alone:.2f} ms/step, with {n_wg} CUs held {duty:.0%} of the time in {burst_us:.0f} us bursts {contended:.2f} ms/step "
+print(f"{os.environ.get('VITK_P8_EVEN_ROUNDS', 'unset')=}, {os.environ.get('VITK_WGRAD_OVERLAP', '1')=}: alone {alone:.2f} ms/step, with {n_wg} CUs held {duty:.0%} of the time in {burst_us:.0f} us bursts {contended:.2f} ms/step "
 	f"(+{100 * (contended / alone - 1):.1f} %; losing exactly the held CU-time would be {ideal:.2f}), alone again {again:.2f}", flush=True)

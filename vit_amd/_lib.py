@@ -50,6 +50,7 @@ SIGNATURES = {
 	"vitk_gemm_uses_bf16_mfma": [POINTER(GemmDesc)],
 	"vitk_gemm_last_kernel": [],
 	"vitk_gemm_workspace_bytes": [],
+	"vitk_gemm_leave_cus_free": [I],
 	"vitk_layernorm_fwd": [P, P, P, P, P, P, P, P, I64, I64, FL, I, P],
 	"vitk_dropout_epoch_set": [P],
 	"vitk_dropout_epoch_advance": [P, P],

@@ -113,6 +113,9 @@ class GradSync:
 		self.launched = []
 		self.hooks = [None] * len(flat.params)
 		if self.active:
+			if flat.param.is_cuda:
+				# the persistent GEMMs leave the CUs they cannot fill a round with to the communication kernels
+				L.load().vitk_gemm_leave_cus_free(1)
 			for i, p in enumerate(flat.params):
 				self.hooks[i] = self._make_hook(i)
 				p.register_post_accumulate_grad_hook(self.hooks[i])
