@@ -224,17 +224,6 @@ int vitk_attention_bwd_noalloc(const void* dout, const void* q, const void* k, c
 	float scale, float dropout_p, uint64_t seed, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------
- * A second stream for the weight-gradient GEMMs.  No counterpart in the reference (autograd runs nn.Linear's two
- * backward products, layers/transformers.py:46-54 and layers/attention.py:28,47, one after the other on one stream).
- * dW = dy^T x of a layer and its dx = dy W are independent: issued on a stream of the LOWEST priority the device offers,
- * the weight-gradient workgroups take the CUs that the persistent input-gradient launch leaves idle in its partly filled
- * last round of tiles, and never displace a workgroup of the caller's main stream that is ready to start.  The stream is
- * created non-blocking (no implicit ordering against the null stream): the caller orders it with events.  low_priority
- * = 0 creates a stream of default priority.  vitk_stream_destroy releases it (after the caller has synchronised it). */
-int vitk_stream_create(void** stream, int low_priority);
-int vitk_stream_destroy(void* stream);
-
-/* ------------------------------------------------------------------------------------------
  * Bandwidth-bound elementwise / reduction kernels.
  */
 /* dst[i] = (dst_dtype) src[i] */
@@ -305,6 +294,10 @@ int vitk_unpatchify(const void* patches, void* images, int64_t B, int64_t C, int
 int vitk_drop_cls_rows(const void* x, void* out, int64_t B, int64_t tokens, int64_t d, int dtype, void* stream);
 /* The same for `lead` leading rows per image (class + distillation token): rows [lead, tokens) -> [B*(tokens-lead), d]. */
 int vitk_drop_lead_rows(const void* x, void* out, int64_t B, int64_t tokens, int64_t d, int64_t lead, int dtype, void* stream);
+/* dst[r * ld_dst + c] += src[r * ld_src + c] for r < rows, c < d: gradients of the class-token rows added into a gradient
+ * of all token rows (the out[:, 0] of models/vit.py:63 seen from the last block, whose other output rows nobody reads:
+ * autograd's backward of that indexing puts the row gradient into an otherwise zero tensor and adds it). */
+int vitk_add_rows(void* dst, const void* src, int64_t rows, int64_t d, int64_t ld_dst, int64_t ld_src, int dtype, void* stream);
 /* Token mean pool x[B, S, d] -> y[B, d] and its backward (models/cvt.py:105). */
 int vitk_mean_pool_fwd(const void* x, void* y, int64_t B, int64_t S, int64_t d, int dtype, void* stream);
 int vitk_mean_pool_bwd(const void* dy, void* dx, int64_t B, int64_t S, int64_t d, int dtype, void* stream);

@@ -64,8 +64,6 @@ SIGNATURES = {
 	"vitk_attention_fwd_dropout": [P, P, P, P, P, I64, I64, I64, I64, I64, I64, I64, I64, I64, FL, FL, ctypes.c_uint64, I, P],
 	"vitk_attention_bwd_dropout": [P, P, P, P, P, P, P, P, P, I64, I64, I64, I64, I64, I64, I64, I64, I64, I64, I64, I64, FL, FL, ctypes.c_uint64, P, I, P],
 	"vitk_attention_bwd_noalloc": [P, P, P, P, P, P, P, P, P, I64, I64, I64, I64, I64, I64, I64, I64, I64, I64, I64, I64, FL, FL, ctypes.c_uint64, I, P],
-	"vitk_stream_create": [POINTER(c_void_p), I],
-	"vitk_stream_destroy": [P],
 	"vitk_scale_by": [P, P, P, I64, I, P],
 	"vitk_cast": [P, P, I64, I, I, P],
 	"vitk_transpose": [P, P, I64, I64, I64, I64, I, P],
@@ -85,6 +83,7 @@ SIGNATURES = {
 	"vitk_unpatchify": [P, P, I64, I64, I64, I64, I, P],
 	"vitk_drop_cls_rows": [P, P, I64, I64, I64, I, P],
 	"vitk_drop_lead_rows": [P, P, I64, I64, I64, I64, I, P],
+	"vitk_add_rows": [P, P, I64, I64, I64, I64, I, P],
 	"vitk_mean_pool_fwd": [P, P, I64, I64, I64, I, P],
 	"vitk_mean_pool_bwd": [P, P, I64, I64, I64, I, P],
 	"vitk_ce_kd_loss": [P, P, P, P, P, I64, I64, FL, FL, FL, I, P],

@@ -703,6 +703,26 @@ extern "C" int vitk_unpatchify(const void* patches, void* images, int64_t B, int
 	});
 }
 
+namespace {
+template <typename T>
+__global__ void add_rows_kernel(T* __restrict__ dst, const T* __restrict__ src, int64_t rows, int64_t d, int64_t ld_dst, int64_t ld_src) {
+	for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < rows * d; i += (int64_t)gridDim.x * blockDim.x) {
+		const int64_t r = i / d, c = i - r * d;
+		dst[r * ld_dst + c] = from_f32<T>(to_f32<T>(dst[r * ld_dst + c]) + to_f32<T>(src[r * ld_src + c]));
+	}
+}
+}  // namespace
+
+extern "C" int vitk_add_rows(void* dst, const void* src, int64_t rows, int64_t d, int64_t ld_dst, int64_t ld_src, int dtype, void* stream) {
+	VITK_REQUIRE(dst && src, VITK_ERR_NULL);
+	VITK_REQUIRE(rows > 0 && d > 0 && ld_dst >= d && ld_src >= d, VITK_ERR_SHAPE);
+	DISPATCH_T(dtype, {
+		hipLaunchKernelGGL((add_rows_kernel<T>), dim3(vitk_stream_grid(rows * d, 256)), dim3(256), 0, (hipStream_t)stream, (T*)dst, (const T*)src, rows, d, ld_dst, ld_src);
+		VITK_CHECK_LAUNCH();
+		return VITK_OK;
+	});
+}
+
 extern "C" int vitk_drop_lead_rows(const void* x, void* out, int64_t B, int64_t tokens, int64_t d, int64_t lead, int dtype, void* stream) {
 	VITK_REQUIRE(x && out, VITK_ERR_NULL);
 	VITK_REQUIRE(B > 0 && lead >= 1 && tokens > lead && d > 0, VITK_ERR_SHAPE);

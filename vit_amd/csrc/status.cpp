@@ -54,22 +54,3 @@ extern "C" int vitk_dropout_epoch_advance(uint32_t* epoch, void* stream) {
 	hipError_t e = hipGetLastError();
 	return e == hipSuccess ? VITK_OK : VITK_ERR_HIP - (int)e;
 }
-
-// ---- streams for work that runs beside the caller's main stream --------------------------------------------------------
-extern "C" int vitk_stream_create(void** stream, int low_priority) {
-	if (stream == nullptr) return VITK_ERR_NULL;
-	int least = 0, greatest = 0;
-	hipError_t e = hipDeviceGetStreamPriorityRange(&least, &greatest);  // numerically larger = lower priority
-	if (e != hipSuccess) return VITK_ERR_HIP - (int)e;
-	hipStream_t s = nullptr;
-	e = hipStreamCreateWithPriority(&s, hipStreamNonBlocking, low_priority ? least : 0);
-	if (e != hipSuccess) return VITK_ERR_HIP - (int)e;
-	*stream = (void*)s;
-	return VITK_OK;
-}
-
-extern "C" int vitk_stream_destroy(void* stream) {
-	if (stream == nullptr) return VITK_ERR_NULL;
-	hipError_t e = hipStreamDestroy((hipStream_t)stream);
-	return e == hipSuccess ? VITK_OK : VITK_ERR_HIP - (int)e;
-}

@@ -353,7 +353,7 @@ class FlatAdamW(torch.optim.Optimizer):
 		checkpoint.load_optimizer_state_dict(self, sd)
 
 	def step(self, closure=None, grad_scale=1.0, pipelined=False):
-		"""pipelined: issue the step on the low-priority second stream, piece by piece in the order the next forward pass
+		"""pipelined: issue the step on the second stream, piece by piece in the order the next forward pass
 		reads the parameters, clearing each gradient as it is consumed (no zero_grad pass), and return at once: every
 		kernel of this package that reads a parameter first makes its stream wait for that parameter's piece
 		(ops.weight_as), so the next forward starts while the later blocks are still being updated, and the update runs

@@ -45,6 +45,20 @@ class ViTBlock(nn.Module):
 			return True
 		return not any(m.active() for _, m in self._dropout_slots())
 
+	def forward_class_rows(self, x):
+		"""The block as the LAST block of a model whose head reads token row 0 only: returns ([B, 1, d], 0.0), the rows
+		of the block's output that are read (ops.ViTLastBlockFn), or None when this block cannot take that form (LayerScale,
+		an active dropout, another attention or norm module) and the caller should run forward()."""
+		if not self._fusable() or self.attn_layer_scale is not None or self.ff_layer_scale is not None or any(m.active() for _, m in self._dropout_slots()):
+			return None
+		kind, n1w, n1b, eps, off = norm_spec(self.attn_norm)
+		kind2, n2w, n2b, eps2, off2 = norm_spec(self.ff_norm)
+		assert (kind, eps, off) == (kind2, eps2, off2)
+		cfg = (kind, eps, off, self.attn.n_head, self.ff.act_code, self.ff.gated, None)
+		y = ops.ViTLastBlockFn.apply(x, n1w, n1b, self.attn.qkv_proj.weight, self.attn.out_proj.weight, self.attn.out_proj.bias,
+			n2w, n2b, self.ff.fc_in.weight, self.ff.fc_in.bias, self.ff.fc_out.weight, self.ff.fc_out.bias, cfg)
+		return y, 0.0
+
 	def forward(self, x, h=None, w=None):
 		if self._fusable():
 			# {slot: (p, seed)} of the dropouts that are on right now (training mode, p > 0); fresh seeds per call, drawn

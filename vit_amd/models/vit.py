@@ -5,12 +5,17 @@ The reference's forward materialises patches, loops over the batch in Python to 
 token and repeats pos_embed; here the patch GEMM gathers pixels in its A-tile loader, adds bias and
 pos_embed in its epilogue and writes straight into rows 1.. of the token buffer, a small kernel fills
 row 0, and the classifier reads row 0 in place through the row stride."""
+import os
+
 import torch
 import torch.nn as nn
 
 from .. import ops
 from ..layers.attention import QuadrangleAttention
 from ..layers.vit import ViTBlock
+
+
+CLASS_ROWS_LAST_BLOCK = os.environ.get("VITK_CLASS_ROWS_LAST_BLOCK", "1") != "0"  # see ViT.forward
 
 
 class ViT(nn.Module):
@@ -37,6 +42,9 @@ class ViT(nn.Module):
 
 	def forward(self, images):
 		x = ops.PatchEmbedFn.apply(images, self.linear_mapper.weight, self.linear_mapper.bias, self.class_token, self.pos_embed, self.n_patch)
-		for block in self.blocks:
-			x, _ = block(x)
+		n = len(self.blocks)
+		for i, block in enumerate(self.blocks):
+			# the head reads out[:, 0] only (models/vit.py:63 there): the last block computes the rows that are read
+			last = block.forward_class_rows(x) if (i == n - 1 and CLASS_ROWS_LAST_BLOCK) else None
+			x, _ = last if last is not None else block(x)
 		return ops.ClsHeadFn.apply(x, self.mlp.weight, self.mlp.bias)

@@ -6,7 +6,6 @@ dtype of the activations (float32 or bfloat16); weights are cast to it through a
 cache, parameter gradients are produced in float32 and cast to the parameter dtype if needed.
 """
 import contextlib
-import ctypes
 import math
 import os
 import weakref
@@ -316,7 +315,7 @@ def gemm_workspace(device):
 # dW = dy^T x of a Linear and its dx = dy W are independent, and nothing reads dW before the optimizer step (or the
 # gradient all-reduce).  The persistent input-gradient GEMM of a 768-wide layer over 50 k tokens has 591 tiles for 256 CUs:
 # its third round keeps 79 CUs busy.  Weight-gradient GEMMs that add into gradient sinks are therefore issued on a stream
-# of the lowest priority: their workgroups (one tile x K slice each, not persistent) start wherever a CU is free and
+# of its own: their workgroups (one tile x K slice each, not persistent) start wherever a CU is free and
 # fill those rounds, the tails of the attention kernels and the bandwidth-bound kernels in between.  The stream is joined
 # at the end of the backward pass (autograd's final callback), before anything can read a gradient.
 WGRAD_OVERLAP = os.environ.get("VITK_WGRAD_OVERLAP", "1") != "0"
@@ -331,9 +330,10 @@ class _WgradLane:
 	sections = 0  # launches handed to a second stream so far (all devices)
 
 	def __init__(self, device):
-		h = ctypes.c_void_p()
-		L.check(L.load().vitk_stream_create(ctypes.byref(h), 1))
-		self.stream = torch.cuda.ExternalStream(h.value, device=device)
+		# a stream of torch's own pool.  (A HIP stream of the lowest priority created outside torch and wrapped as
+		# torch.cuda.ExternalStream measured the same step time, but cross-stream waits on it intermittently never returned, or
+		# returned early, in a process that had captured HIP graphs before: dropped.)
+		self.stream = torch.cuda.Stream(device=device)
 		self.held = []  # operands of launches that may still run (the caching allocator must not hand them out again)
 		self.hooked = False  # the end-of-backward join is queued
 		self.last = None  # event behind the newest launch
@@ -401,7 +401,7 @@ def wgrad_mark(dy, x, dw_out):
 
 
 def second_stream(device):
-	"""The low-priority second stream of `device` (created on first use)."""
+	"""The second stream of `device` (created on first use)."""
 	lane = _wgrad_lanes.get(device.index)
 	if lane is None:
 		lane = _wgrad_lanes[device.index] = _WgradLane(device)
@@ -957,6 +957,95 @@ class ViTBlockFn(torch.autograd.Function):
 			return _sink_done(p, sk[name]) if sk[name] is not None else grad_as(g, p)
 		return (dx0, out("n1w", dn1w, n1w), out("n1b", dn1b, n1b), out("wqkv", dwqkv, wqkv), out("wo", dwo, wo), out("bo", dbo, bo), grad_as(dls1, ls1),
 			out("n2w", dn2w, n2w), out("n2b", dn2b, n2b), out("w1", dw1, w1), out("b1", db1, b1), out("w2", dw2, w2), out("b2", db2, b2), grad_as(dls2, ls2), None)
+
+
+def add_rows(dst, src):
+	"""dst[r, :] += src[r, :] for two [rows, d] views with unit inner stride (any row strides)."""
+	rows, d = src.shape
+	assert dst.shape == src.shape and dst.stride(1) == 1 and src.stride(1) == 1 and dst.dtype == src.dtype
+	L.check(L.load().vitk_add_rows(L.ptr(dst), L.ptr(src), rows, d, dst.stride(0), src.stride(0), L.dtype_code(dst.dtype), L.stream()))
+
+
+def _dgrad_rows(dy, w, r0, r1):
+	"""dy @ w[r0:r1, :] for a Linear weight w [out, in] in the compute dtype (dy: [M, r1 - r0]): the input gradient through
+	the output features r0 .. r1 of a fused projection.  Many bf16 tokens read the kept transposed copy, as linear_dgrad."""
+	M, N = dy.shape
+	K = w.shape[1]
+	assert N == r1 - r0 and dy.stride(1) == 1
+	if DGRAD_TRANSPOSED_WEIGHTS and dy.dtype == torch.bfloat16 and M >= 4096 and N % 64 == 0 and K >= DGRAD_T_MIN and N >= DGRAD_T_MIN:
+		wt = weight_t(w)  # [in, out]: B(n = input feature, k = output feature) K-major with row stride `out`
+		dx = torch.empty((M, K), dtype=dy.dtype, device=dy.device)
+		gemm(dy, wt[:, r0:r1], dx, M, K, N, dy.stride(0), wt.stride(0), K)
+		return dx
+	return linear_dgrad(dy, w[r0:r1])
+
+
+class ViTLastBlockFn(torch.autograd.Function):
+	"""The LAST pre-norm block of a ViT whose head reads the class-token row only (models/vit.py:54-65 there: the loop over
+	the blocks, then `out = out[:, 0]`).  Of the last block's output only row 0 of every sample is ever read, so of its
+	work only what that row depends on is done: the norm and the key / value projection of ALL tokens (the class token's
+	query attends to every key), and for the class rows alone the query projection, the attention row, the output
+	projection, the second norm and the feed-forward.  Logits, loss and every parameter / input gradient are those of
+	the full block (the rows left out have zero upstream gradient in the reference as well); 10 of the block's 12
+	d x d-sized products shrink from B * S rows to B.  Returns [B, 1, d].  No LayerScale, no active dropout (the caller
+	falls back to ViTBlockFn)."""
+
+	@staticmethod
+	def forward(ctx, x, n1w, n1b, wqkv, wo, bo, n2w, n2b, w1, b1, w2, b2, cfg):
+		L.require_gpu(x, wqkv)
+		kind, eps, unit_offset, n_head, act, gated = cfg[:6]
+		dt = compute_dtype(x)
+		B, S, d = x.shape
+		dh = d // n_head
+		x0 = _flat(cast(x, dt))
+		wqkv_c, wo_c, w1_c, w2_c = (weight_as(t, dt) for t in (wqkv, wo, w1, w2))
+		n1, _, mean1, rstd1 = norm_fwd(x0, f32(n1w), f32(n1b), kind, eps, unit_offset)
+		kv = linear_fwd(n1, wqkv_c[d:])  # keys and values of every token
+		q = linear_fwd(n1[::S], wqkv_c[:d])  # queries of the class rows (read in place through the row stride S * d)
+		o, lse = attention_fwd(q, kv[:, :d], kv[:, d:], B, n_head, 1, S, dh)
+		x1 = linear_fwd(o, wo_c, f32(bo), residual=x0[::S])
+		n2, _, mean2, rstd2 = norm_fwd(x1, f32(n2w), f32(n2b), kind, eps, unit_offset)
+		x2, u, a = _ffn_forward(n2, w1_c, f32(b1), w2_c, f32(b2), act, gated, residual=x1)
+		ctx.save_for_backward(x0, n1, mean1, rstd1, kv, q, o, lse, x1, n2, mean2, rstd2, u, a, n1w, wqkv, wo, n2w, w1, w2)
+		ctx.meta = (x.shape, x.dtype, n1b, bo, n2b, b1, b2, cfg, dt)
+		return x2.reshape(B, 1, d)
+
+	@staticmethod
+	def backward(ctx, dy):
+		(x0, n1, mean1, rstd1, kv, q, o, lse, x1, n2, mean2, rstd2, u, a, n1w, wqkv, wo, n2w, w1, w2) = ctx.saved_tensors
+		(B, S, d), xdtype, n1b, bo, n2b, b1, b2, cfg, dt = ctx.meta
+		kind, eps, unit_offset, n_head, act, gated = cfg[:6]
+		dh = d // n_head
+		wqkv_c, wo_c, w1_c, w2_c = (weight_as(t, dt) for t in (wqkv, wo, w1, w2))
+		dx2 = _flat(cast(dy, dt))  # [B, d]
+		sk = {n: _sink(t) for n, t in (("n1w", n1w), ("n1b", n1b), ("wqkv", wqkv), ("wo", wo), ("bo", bo), ("n2w", n2w), ("n2b", n2b), ("w1", w1), ("b1", b1),
+			("w2", w2), ("b2", b2))}
+		buf = {n: (v[0] if v is not None else None) for n, v in sk.items()}
+		# class rows: feed-forward branch, second norm, output projection, the attention row
+		dn2, dw1, db1, dw2, db2 = _ffn_backward(dx2, n2, u, a, w1_c, w2_c, act, gated, outs=(buf["w1"], buf["b1"], buf["w2"], buf["b2"]))
+		dx1, dn2w, dn2b = norm_bwd(dn2, x1, f32(n2w), mean2, rstd2, kind, unit_offset, dres=dx2, dw_out=buf["n2w"], db_out=buf["n2b"])
+		dwo, dbo = linear_wgrad(dx1, o, bias_grad=True, dw_out=buf["wo"], db_out=buf["bo"])
+		do = linear_dgrad(dx1, wo_c)
+		dq = torch.empty_like(q)
+		dkv = torch.empty_like(kv)
+		attention_bwd(do, q, kv[:, :d], kv[:, d:], o, lse, dq, dkv[:, :d], dkv[:, d:], B, n_head, 1, S, dh)
+		# fused qkv projection: weight rows [0, d) from the class rows' queries, rows [d, 3d) from every token's keys and values
+		dwqkv = buf["wqkv"] if buf["wqkv"] is not None else torch.zeros((3 * d, d), dtype=torch.float32, device=dy.device)
+		ready = wgrad_mark(dkv, n1, buf["wqkv"])
+		dn1 = _dgrad_rows(dkv, wqkv_c, d, 3 * d)
+		linear_wgrad(dkv, n1, dw_out=dwqkv[d:], overlap=buf["wqkv"] is not None, after=ready)
+		linear_wgrad(dq, n1[::S], dw_out=dwqkv[:d])
+		add_rows(dn1[::S], _dgrad_rows(dq, wqkv_c, 0, d))
+		dx0, dn1w, dn1b = norm_bwd(dn1, x0, f32(n1w), mean1, rstd1, kind, unit_offset, dw_out=buf["n1w"], db_out=buf["n1b"])
+		add_rows(dx0[::S], dx1)  # the residual path exists for the class rows only
+		dx0 = dx0.reshape(B, S, d)
+		if dx0.dtype != xdtype:
+			dx0 = cast(dx0, xdtype)
+
+		def out(name, g, p):
+			return _sink_done(p, sk[name]) if sk[name] is not None else grad_as(g, p)
+		return (dx0, out("n1w", dn1w, n1w), out("n1b", dn1b, n1b), out("wqkv", dwqkv, wqkv), out("wo", dwo, wo), out("bo", dbo, bo),
+			out("n2w", dn2w, n2w), out("n2b", dn2b, n2b), out("w1", dw1, w1), out("b1", db1, b1), out("w2", dw2, w2), out("b2", db2, b2), None)
 
 
 class PatchEmbedFn(torch.autograd.Function):
