@@ -42,12 +42,15 @@ COATNET = dict(dims=[64, 96, 192, 384, 768], depths=[2, 2, 3, 5, 2], num_heads=3
 PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak of one MI355X
 
 
-def train_flops_per_image(c):
+def train_flops_per_image(c, class_rows_last_block=False):
+	"""3 x the forward's 2 x MAC count.  class_rows_last_block: the last block computes only what the class-token row of its
+	output depends on (keys / values of all tokens; query, attention row, projection and feed-forward of one row)."""
 	d, f, L_ = c["d_model"], c["d_ff"], c["n_block"]
 	n = c["n_patch"] ** 2 + 1
 	p = c["chw"][1] // c["n_patch"]
 	block = 2 * n * d * 3 * d + 4 * n * n * d + 2 * n * d * d + 4 * n * d * f
-	fwd = L_ * block + 2 * (n - 1) * (c["chw"][0] * p * p) * d + 2 * d * c["out_d"]
+	last = 2 * n * d * 2 * d + 2 * d * d + 4 * n * d + 2 * d * d + 4 * d * f if class_rows_last_block else block
+	fwd = (L_ - 1) * block + last + 2 * (n - 1) * (c["chw"][0] * p * p) * d + 2 * d * c["out_d"]
 	return 3.0 * fwd
 
 
@@ -151,6 +154,7 @@ def main():
 	ap.add_argument("--dropout", type=float, default=0.0, help="config.dropout (attention-probability, branch and feed-forward dropouts)")
 	ap.add_argument("--no-cpu-baseline", action="store_true")
 	ap.add_argument("--no-kernel-timing", action="store_true")
+	ap.add_argument("--full-last-block", action="store_true", help="ViT: run the last block on all token rows (default: only what the class-token row, the one row the head reads, depends on; same logits and gradients)")
 	ap.add_argument("--no-pipelined-step", action="store_true", help="finish the optimizer step before the next forward starts (default: it runs under it, on the second stream)")
 	ap.add_argument("--lr", type=float, default=1e-4)
 	ap.add_argument("--launcher-selftest", action="store_true", help=argparse.SUPPRESS)
@@ -173,6 +177,9 @@ def main():
 
 	from vit_amd import dp, ops
 	from vit_amd.models import ViT
+	import vit_amd.models.vit as vit_model
+	if args.full_last_block:
+		vit_model.CLASS_ROWS_LAST_BLOCK = False
 
 	is_cvt = args.config == "cvt"
 	is_deit = args.config == "deit_tiny"
@@ -300,7 +307,9 @@ def main():
 			"first_loss": None if first_loss is None else round(first_loss, 4), "final_loss": round(final_loss, 4), "lr": args.lr}), flush=True)
 	elif rank == 0:
 		value = batch * world * args.steps / elapsed
-		flops_img = train_flops_per_image(c)
+		class_rows = vit_model.CLASS_ROWS_LAST_BLOCK and args.dropout == 0.0
+		flops_img = train_flops_per_image(c, class_rows)  # FLOPs the step executes
+		flops_nominal = train_flops_per_image(c)  # FLOPs of the reference's formulation (every block on every token row)
 		out = {
 			"metric": "train images/sec (node) ViT-B/16 224x224 bf16" if args.config == "vit_b16" else "train images/sec (node) ViT-Tiny/4 32x32 bf16",
 			"value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -308,8 +317,11 @@ def main():
 			"dtype": "bf16", "data": "synthetic",
 			"config": {"workload": f"{args.config}: ViT d{c['d_model']}/h{c['n_head']}/L{c['n_block']}/ff{c['d_ff']} patch{c['chw'][1] // c['n_patch']} at {c['chw'][1]}x{c['chw'][2]}, "
 				f"{c['n_patch'] ** 2 + 1} tokens, fwd+CE+bwd+AdamW, fp32 master weights, bf16 activations", "global_batch": batch * world, "per_gpu_batch": batch,
-				"parallelism": f"dp{world}", "hip_graph": bool(args.graph), "dropout": args.dropout},
+				"parallelism": f"dp{world}", "hip_graph": bool(args.graph), "dropout": args.dropout,
+				"last_block": "class rows only: the head reads out[:, 0], the last block computes what that row depends on (same logits and gradients as the full block; --full-last-block runs all rows)" if class_rows else "all token rows",
+				"optimizer_step": "runs under the next forward on the second stream" if not args.no_pipelined_step and not args.graph else "finished before the next forward"},
 			"train_gflop_per_image": round(flops_img / 1e9, 3),
+			"train_gflop_per_image_all_rows": round(flops_nominal / 1e9, 3),
 			"mfma_util_pct": round(100.0 * value * flops_img / (world * PEAK_BF16_TFLOPS * 1e12), 2),
 			"first_loss": None if first_loss is None else round(first_loss, 4), "final_loss": round(final_loss, 4), "lr": args.lr,
 		}

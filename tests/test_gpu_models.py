@@ -295,6 +295,56 @@ def test_fused_block_with_dropout_matches_composition(gpu, dtype, act):
 	assert relerr(y1, y_eval) > 1e-2
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("variant", ["ln_gelu", "rms_silu", "ln_swiglu", "many_rows"])
+def test_last_block_in_class_rows_form_is_the_full_block_at_row_zero(gpu, dtype, variant):
+	"""ViTBlock.forward_class_rows (the last block of a ViT, whose output the head reads at token row 0 only:
+	models/vit.py:54-65 there) against the full block followed by [:, 0]: same rows, same gradient for every parameter
+	and for every input token, for LayerNorm / RMSNorm, plain and gated feed-forward, and at a row count where the key /
+	value projection runs on the large-tile kernels (many_rows: 32 x 197 tokens, 768 wide, head size 64)."""
+	from vit_amd.layers import MHA, RMSNorm, ViTBlock
+
+	class Cfg:
+		d_model = 128; n_head = 2; d_ff = 256; dropout = 0.0; activation = "gelu"; norm = nn.LayerNorm
+		use_layer_scale = False; use_qk_norm = False; attention = MHA
+	B, S = 5, 23
+	if variant == "rms_silu":
+		Cfg.norm, Cfg.activation = RMSNorm, "silu"
+	elif variant == "ln_swiglu":
+		Cfg.activation = "swiglu"
+	elif variant == "many_rows":
+		Cfg.d_model, Cfg.n_head, Cfg.d_ff = 768, 12, 3072
+		B, S = 32, 197
+	d = Cfg.d_model
+	torch.manual_seed(0)
+	blk = ViTBlock(Cfg()).to(gpu).train()
+	x = torch.randn(B, S, d, device=gpu).to(dtype)
+	gy = torch.randn(B, d, device=gpu).to(dtype)
+	results = []
+	for cls_rows in (False, True):
+		xi = x.clone().requires_grad_()
+		blk.zero_grad()
+		if cls_rows:
+			out = blk.forward_class_rows(xi)
+			assert out is not None and out[0].shape == (B, 1, d)
+			y = out[0][:, 0]
+		else:
+			y = blk(xi)[0][:, 0]
+		y.backward(gy)
+		results.append((y.detach(), xi.grad, {k: p.grad.clone() for k, p in blk.named_parameters()}))
+	(y1, dx1, g1), (y2, dx2, g2) = results
+	tol = 1e-5 if dtype == torch.float32 else 2e-2
+	assert relerr(y2, y1) < tol and relerr(dx2, dx1) < tol
+	assert float(dx1[:, 1:].abs().max()) > 0  # (the other tokens do receive gradient: through the keys and values)
+	for k in g1:
+		assert relerr(g2[k], g1[k]) < (1e-4 if dtype == torch.float32 else 4e-2), k
+	# LayerScale or an active dropout: the block declines and the caller runs the full form
+	Cfg.use_layer_scale = True
+	assert ViTBlock(Cfg()).to(gpu).forward_class_rows(x) is None
+	Cfg.use_layer_scale, Cfg.dropout = False, 0.1
+	assert ViTBlock(Cfg()).to(gpu).train().forward_class_rows(x) is None
+
+
 def make_cvt(c, gpu):
 	from vit_amd.layers import RMSNorm
 	from vit_amd.models import CvT
