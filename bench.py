@@ -268,6 +268,8 @@ def main():
 		# the main stream: a launch that shares the CUs with a weight-gradient GEMM of the second stream has no duration of
 		# its own to divide its FLOPs by
 		ops.GEMM_PROFILE, ops.GEMM_PROFILE_SERIAL = [], True
+		trainer.pipelined_step = False  # (the optimizer does not share the CUs with the next forward's GEMMs either)
+		trainer.wait_step()
 		profiled_steps = min(args.steps, 10)
 		for _ in range(profiled_steps):
 			step()

@@ -10,7 +10,7 @@ namecol = "name" if "name" in cols else "kernel_name"
 qcol = "queue_id" if "queue_id" in cols else ("stream_id" if "stream_id" in cols else None)
 rows = c.execute(f"select start, end, {namecol}" + (f", {qcol}" if qcol else ", 0") + " from kernels order by start").fetchall()
 # steady state: from the end of one optimizer kernel to the end of the last one (whole training steps), skipping the first ones
-ad = [r[1] for r in rows if "adamw_kernel" in r[2]]
+ad = [r[1] for r in rows if "adamw_advance" in r[2]]  # one per optimizer step
 if len(ad) >= 4:
 	first = ad[max(1, int(len(ad) * skip))]
 	rows = [r for r in rows if r[0] >= first and r[1] <= ad[-1]]
