@@ -1,0 +1,81 @@
+"""Two data-parallel ranks on ONE GPU over gloo (device tensors): the multi-rank control flow of dp.Trainer -- replica
+broadcast, gradient buckets all-reduced from the backward hooks while weight-gradient GEMMs run on the second stream,
+pipelined optimizer step -- with a real reduction between two processes.  Each rank takes half of a fixed global batch;
+after every step the ranks must hold identical parameters, and these must follow a single-process run over the whole
+batch.  Start under the launcher:
+python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29541 tools/dp_two_ranks_one_gpu.py"""
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(dev)
+dist.init_process_group("gloo")
+from vit_amd import dp, ops  # noqa: E402
+from vit_amd.models import ViT  # noqa: E402
+
+ops.WGRAD_OVERLAP_MIN_FLOPS = float(os.environ.get("MIN_FLOPS", "0"))  # every fused-block weight gradient on the second stream
+cfg = dict(bench.CONFIGS["vit_tiny"], n_block=4)
+steps, per_rank = 4, 16
+g = torch.Generator().manual_seed(3)
+xs = torch.randn(steps, world * per_rank, *cfg["chw"], generator=g)
+ys = torch.randint(0, cfg["out_d"], (steps, world * per_rank), generator=g)
+
+
+def run(sharded, pipelined):
+	ops.clear_grad_sinks()
+	torch.manual_seed(100 + (rank if sharded else 0))  # different initial weights per rank: the broadcast must equalise them
+	model = ViT(bench.make_config(cfg)).to(dev)
+	if sharded:
+		trainer = dp.Trainer(model, lr=1e-3, weight_decay=0.05, bucket_bytes=256 << 10, pipelined_step=pipelined)
+	else:
+		was, dist.is_initialized = dist.is_initialized, (lambda: False)  # a plain single-process trainer
+		try:
+			if rank != 0:
+				torch.manual_seed(100)
+				model = ViT(bench.make_config(cfg)).to(dev)
+			trainer = dp.Trainer(model, lr=1e-3, weight_decay=0.05, pipelined_step=pipelined)
+		finally:
+			dist.is_initialized = was
+	losses = []
+	for s in range(steps):
+		x, y = xs[s], ys[s]
+		if sharded:
+			x, y = x[rank * per_rank:(rank + 1) * per_rank], y[rank * per_rank:(rank + 1) * per_rank]
+		trainer.zero_grad()
+		with torch.autocast("cuda", dtype=torch.bfloat16):
+			loss = ops.cross_entropy(model(x.to(dev)), y.to(dev))
+		loss.backward()
+		trainer.step()
+		losses.append(float(loss.detach()))
+	trainer.wait_step()
+	torch.cuda.synchronize()
+	out = trainer.flat.param.clone(), len(trainer.flat.buckets), list(trainer.sync.launched), losses
+	trainer.close()
+	return out
+
+
+ok = True
+for pipelined in (False, True):
+	p_dp, nb, _, l_dp = run(True, pipelined)
+	gathered = [torch.empty_like(p_dp).cpu() for _ in range(world)]
+	dist.all_gather(gathered, p_dp.cpu())
+	same = max(float((t - gathered[0]).abs().max()) for t in gathered)
+	p_one, _, _, l_one = run(False, pipelined)
+	err = float((p_dp - p_one).abs().max() / p_one.abs().max())
+	if rank == 0:
+		print(f"pipelined_step={pipelined}: {nb} buckets, replicas differ by {same:.1e} after {steps} steps, sharded vs single-process parameters {err:.2e}, "
+			f"second-stream launches so far {ops.wgrad_sections()}, losses (rank 0 shard / whole batch) {[round(v, 4) for v in l_dp]} / {[round(v, 4) for v in l_one]}", flush=True)
+	ok = ok and same == 0.0 and err < 2e-3
+dist.barrier()
+dist.destroy_process_group()
+if rank == 0:
+	print("OK" if ok else "MISMATCH", flush=True)
+sys.exit(0 if ok else 1)
