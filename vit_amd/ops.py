@@ -777,21 +777,21 @@ def _ffn_forward(x2, w1, b1, w2, b2, act, gated, residual=None, gamma=None, drop
 def _ffn_backward(dy2, x2, u, a, w1, w2, act, gated, need_dx=True, outs=(None, None, None, None), drop1=(0.0, 0)):
 	"""Returns (dx, dw1, db1, dw2, db2) with float32 parameter gradients.  outs = buffers to accumulate
 	(dw1, db1, dw2, db2) into (gradient sinks) or None each.  `a` is fc_out's input (after dropout1)."""
-	# each weight-gradient product is issued BEHIND the input-gradient product that shares its dy (the persistent kernel
-	# gets the CUs first, the weight gradient fills what its last round leaves idle) but depends only on the mark before it
-	ready = wgrad_mark(dy2, a, outs[2])
 	if gated:
 		da = linear_dgrad(dy2, w2)
-		dw2, db2 = linear_wgrad(dy2, a, bias_grad=True, dw_out=outs[2], db_out=outs[3], overlap=True, after=ready)
 		if drop1[0] > 0.0:
 			dropout_add(da, None, drop1[0], drop1[1], out=da)
 		du = gated_act_bwd(da, u, w2.shape[1], act)
 	else:
 		# the dropout mask and the activation derivative are both elementwise factors of the same epilogue
 		du = linear_dgrad(dy2, w2, act=act, pre=u, drop=(drop1,))
-		dw2, db2 = linear_wgrad(dy2, a, bias_grad=True, dw_out=outs[2], db_out=outs[3], overlap=True, after=ready)
+	# Both weight-gradient products of the branch are issued BEHIND its second input-gradient launch (the persistent kernel
+	# gets the CUs first, the weight gradients fill what its partly filled last round leaves idle) and depend on ONE mark
+	# (du complete, and dy2 with it): a mark is a marker packet on the main stream and costs the launch behind it 6-7 us
+	# (two marks per branch, each weight gradient right behind its own input-gradient launch: 0.14 ms more per ViT-B/16 step)
 	ready = wgrad_mark(du, x2, outs[0])
 	dx = linear_dgrad(du, w1) if need_dx else None
+	dw2, db2 = linear_wgrad(dy2, a, bias_grad=True, dw_out=outs[2], db_out=outs[3], overlap=True, after=ready)
 	dw1, db1 = linear_wgrad(du, x2, bias_grad=True, dw_out=outs[0], db_out=outs[1], overlap=True, after=ready)
 	return dx, dw1, db1, dw2, db2
 
@@ -838,13 +838,12 @@ def _mha_backward(dy2, x2, qkv, o, lse, wqkv, wo, B, S, n_head, need_dx=True, ou
 	"""Returns (dx, dwqkv, dwo, dbo).  outs = buffers to accumulate (dwqkv, dwo, dbo) into (gradient sinks) or None."""
 	d = x2.shape[1]
 	dh = d // n_head
-	ready = wgrad_mark(dy2, o, outs[1])  # (weight gradients behind the input-gradient launches, as in _ffn_backward)
 	do = linear_dgrad(dy2, wo)
-	dwo, dbo = linear_wgrad(dy2, o, bias_grad=True, dw_out=outs[1], db_out=outs[2], overlap=True, after=ready)
 	dqkv = torch.empty_like(qkv)
 	attention_bwd(do, qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], o, lse, dqkv[:, :d], dqkv[:, d:2 * d], dqkv[:, 2 * d:], B, n_head, S, S, dh, drop=drop)
-	ready = wgrad_mark(dqkv, x2, outs[0])
+	ready = wgrad_mark(dqkv, x2, outs[0])  # (one mark for both weight-gradient products, behind the input-gradient launch: see _ffn_backward)
 	dx = linear_dgrad(dqkv, wqkv) if need_dx else None
+	dwo, dbo = linear_wgrad(dy2, o, bias_grad=True, dw_out=outs[1], db_out=outs[2], overlap=True, after=ready)
 	dwqkv = linear_wgrad(dqkv, x2, dw_out=outs[0], overlap=True, after=ready)
 	return dx, dwqkv, dwo, dbo
 
