@@ -230,42 +230,72 @@ __global__ __launch_bounds__(1024) void attn_fwd_mfma_kernel(AttnArgs a) {
 // ---------------------------------------------------------------------------------------------------------------
 // backward: dQ (query on the lane)
 // ---------------------------------------------------------------------------------------------------------------
+// A workgroup walks `a.heads_per_wg` consecutive (batch, head) pairs like the forward kernel: two buffers of a K and a V
+// image filled by LDS-DMA (the next pair's images are in flight while this pair is worked on), one 16-query tile per wave,
+// whose rows of Q, dO and O for the next pair are already in registers.
 template <int KT2, bool DROP>
 __global__ __launch_bounds__(1024) void attn_bwd_dq_mfma_kernel(AttnArgs a) {
 	if constexpr (DROP) attn_enter(a);
 	extern __shared__ __attribute__((aligned(16))) char smem[];
-	char* Ks = smem;
-	char* Vs = smem + KT2 * 32 * 128;
-	const int b = blockIdx.x / a.n_head, h = blockIdx.x % a.n_head;
-	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+	constexpr int IMG = KT2 * 32 * 128;  // one image
+	const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nwaves = blockDim.x >> 6;
 	const int g = lane >> 4;
-	const bf16_t* kb = reinterpret_cast<const bf16_t*>(a.k) + (int64_t)b * a.Skv * a.ldk + h * DH;
-	const bf16_t* vb = reinterpret_cast<const bf16_t*>(a.v) + (int64_t)b * a.Skv * a.ldv + h * DH;
-	stage_image(Ks, kb, a.ldk, a.Skv, KT2 * 32);
-	stage_image(Vs, vb, a.ldv, a.Skv, KT2 * 32);
-	__syncthreads();
+	const int n_bh = a.B * a.n_head;
+	const int bh0 = blockIdx.x * a.heads_per_wg;
+	const int bh1 = min(n_bh, bh0 + a.heads_per_wg);
 	const float c = a.scale * LOG2E;
-	const int n_qtiles = (a.Sq + 15) >> 4;
-	for (int qt = wave; qt < n_qtiles; qt += nwaves) {
-		const int q = qt * 16 + (lane & 15);
-		const int qc = q < a.Sq ? q : a.Sq - 1;
+	const int n_qtiles = (a.Sq + 15) >> 4;  // <= number of waves: one query tile per wave and pair
+	const bool active = wave < n_qtiles;
+	const int q = wave * 16 + (lane & 15);
+	const int qc = q < a.Sq ? q : a.Sq - 1;
+
+	auto stage = [&](int bh, int buf) {
+		const int b = bh / a.n_head, h = bh - b * a.n_head;
+		const bf16_t* kb = reinterpret_cast<const bf16_t*>(a.k) + (int64_t)b * a.Skv * a.ldk + h * DH;
+		const bf16_t* vb = reinterpret_cast<const bf16_t*>(a.v) + (int64_t)b * a.Skv * a.ldv + h * DH;
+		stage_image_dma(smem + buf * 2 * IMG, kb, a.ldk, a.Skv, KT2 * 32, wave, nwaves, lane);
+		stage_image_dma(smem + buf * 2 * IMG + IMG, vb, a.ldv, a.Skv, KT2 * 32, wave, nwaves, lane);
+	};
+	bf16x8 qn0 = {}, qn1 = {}, gn0 = {}, gn1 = {}, on0 = {}, on1 = {};
+	float lsen = 0.f;
+	auto fetch_rows = [&](int bh) {
+		const int b = bh / a.n_head, h = bh - b * a.n_head;
 		const int64_t qrow = (int64_t)b * a.Sq + qc;
 		const bf16_t* qp = reinterpret_cast<const bf16_t*>(a.q) + qrow * a.ldq + h * DH + 8 * g;
 		const bf16_t* gp = reinterpret_cast<const bf16_t*>(a.dout) + qrow * a.ldo + h * DH + 8 * g;
 		const bf16_t* op = reinterpret_cast<const bf16_t*>(a.out) + qrow * a.ldo + h * DH + 8 * g;
-		const bf16x8 qf0 = *reinterpret_cast<const bf16x8*>(qp), qf1 = *reinterpret_cast<const bf16x8*>(qp + 32);
-		const bf16x8 gf0 = *reinterpret_cast<const bf16x8*>(gp), gf1 = *reinterpret_cast<const bf16x8*>(gp + 32);
-		const bf16x8 of0 = *reinterpret_cast<const bf16x8*>(op), of1 = *reinterpret_cast<const bf16x8*>(op + 32);
+		qn0 = *reinterpret_cast<const bf16x8*>(qp), qn1 = *reinterpret_cast<const bf16x8*>(qp + 32);
+		gn0 = *reinterpret_cast<const bf16x8*>(gp), gn1 = *reinterpret_cast<const bf16x8*>(gp + 32);
+		on0 = *reinterpret_cast<const bf16x8*>(op), on1 = *reinterpret_cast<const bf16x8*>(op + 32);
+		lsen = a.lse[(int64_t)bh * a.Sq + qc];
+	};
+	if (bh0 >= bh1) return;  // (grids never exceed the pair count)
+	if (active) fetch_rows(bh0);
+	stage(bh0, 0);
+	for (int bh = bh0; bh < bh1; ++bh) {
+		const int buf = (bh - bh0) & 1;
+		// this pair's images have landed (the barrier's fence drains the DMA, and with it the rows requested before it) and
+		// every wave is done with the other buffer
+		__syncthreads();
+		const bf16x8 qf0 = qn0, qf1 = qn1, gf0 = gn0, gf1 = gn1, of0 = on0, of1 = on1;
+		const float lse2 = lsen * LOG2E;
+		if (bh + 1 < bh1) {
+			stage(bh + 1, buf ^ 1);
+			if (active) fetch_rows(bh + 1);
+		}
+		if (!active) continue;
+		const char* Ks = smem + buf * 2 * IMG;
+		const char* Vs = Ks + IMG;
+		const int b = bh / a.n_head, h = bh - b * a.n_head;
 		float delta = 0.f;
 #pragma unroll
 		for (int j = 0; j < 8; ++j) delta += (float)gf0[j] * (float)of0[j] + (float)gf1[j] * (float)of1[j];
 		delta = group_sum(delta);
-		const float lse2 = a.lse[((int64_t)b * a.n_head + h) * a.Sq + qc] * LOG2E;
 		if (g == 0 && q < a.Sq) {  // row statistics for the dK/dV kernel, which runs after this one
-			a.bwd_scratch[(int64_t)blockIdx.x * a.Sq + q] = lse2;
-			a.bwd_scratch[((int64_t)gridDim.x + blockIdx.x) * a.Sq + q] = delta;
+			a.bwd_scratch[(int64_t)bh * a.Sq + q] = lse2;
+			a.bwd_scratch[((int64_t)n_bh + bh) * a.Sq + q] = delta;
 		}
-		const uint32_t rk = DROP ? attn_row_key(attn_head_key(a, blockIdx.x), q) : 0u;
+		const uint32_t rk = DROP ? attn_row_key(attn_head_key(a, bh), q) : 0u;
 		f32x4 dq[4];
 #pragma unroll
 		for (int dt = 0; dt < 4; ++dt) dq[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -574,16 +604,19 @@ int launch_fwd(const AttnArgs& a0, hipStream_t st) {
 	return VITK_OK;
 }
 template <int T2, bool DROP>
-int launch_dq(const AttnArgs& a, hipStream_t st) {
+int launch_dq(const AttnArgs& a0, hipStream_t st) {
+	AttnArgs a = a0;
 	const int nw = std::min(16, (a.Sq + 15) / 16);
-	const size_t lds = (size_t)2 * T2 * 32 * 128;
+	const int n_bh = a.B * a.n_head;
+	a.heads_per_wg = heads_per_workgroup(n_bh);
+	const size_t lds = (size_t)4 * T2 * 32 * 128;  // two buffers of a K and a V image
 	static bool attr = false;
 	if (!attr) {
 		hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_dq_mfma_kernel<T2, DROP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 		if (e != hipSuccess) return VITK_ERR_HIP - (int)e;
 		attr = true;
 	}
-	hipLaunchKernelGGL((attn_bwd_dq_mfma_kernel<T2, DROP>), dim3((unsigned)(a.B * a.n_head)), dim3(64 * nw), lds, st, a);
+	hipLaunchKernelGGL((attn_bwd_dq_mfma_kernel<T2, DROP>), dim3((unsigned)vitk_cdiv(n_bh, a.heads_per_wg)), dim3(64 * nw), lds, st, a);
 	VITK_CHECK_LAUNCH();
 	return VITK_OK;
 }
