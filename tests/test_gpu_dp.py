@@ -321,7 +321,9 @@ def test_pipelined_optimizer_step_is_the_same_training_run(gpu):
 	for mode in (False, True):
 		ops.clear_grad_sinks()
 		model = _model(gpu)
-		tr = dp.Trainer(model, lr=3e-3, weight_decay=0.05, pipelined_step=mode)
+		# (a small learning rate: the run-to-run noise of the norm gradients' float atomics, amplified through the bf16 rounding
+		# of the weights, moves the losses of two plain runs apart by 1e-3 within five steps at lr 3e-3)
+		tr = dp.Trainer(model, lr=1e-4, weight_decay=0.05, pipelined_step=mode)
 		assert len(tr.opt.pieces) == 3 + CFG["n_block"] + 2 - 1 or len(tr.opt.pieces) >= CFG["n_block"] + 2
 		losses = []
 		for i, (x, y) in enumerate(zip(xs, ys)):
