@@ -215,7 +215,7 @@ def main():
 		teacher = frozen_teacher(20, c["out_d"], tsd).to(dev).to(memory_format=torch.channels_last)
 	else:
 		model = ViT(make_config(c, args.dropout)).to(dev)
-	trainer = dp.Trainer(model, lr=args.lr, weight_decay=0.05, pipelined_step=not args.no_pipelined_step)
+	trainer = dp.Trainer(model, lr=args.lr, weight_decay=0.05, pipelined_step=not args.no_pipelined_step and not args.graph)
 	g = torch.Generator(device="cpu").manual_seed(1234 + rank)
 	x = torch.randn(batch, *c["chw"], generator=g).to(dev)
 	y = torch.randint(0, c["out_d"], (batch,), generator=g).to(dev)

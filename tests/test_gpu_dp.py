@@ -356,3 +356,95 @@ def test_pipelined_optimizer_step_is_the_same_training_run(gpu):
 		assert float((a[i] - b[i]).abs().max()) <= 1e-5 * float(a[i].abs().max()), i
 	assert float((a[3].float() - b[3].float()).abs().max()) <= 1e-2 * float(a[3].float().abs().max())
 	assert float((a[4].float() - b[4].float()).abs().max()) <= 1e-2 * float(a[4].float().abs().max())
+
+
+def test_pipelined_step_hands_over_to_plain_steps_and_to_graph_capture(gpu):
+	"""The pipelined step clears the gradients itself and tells the next zero_grad() to skip its fill.  A plain step after
+	it leaves the gradients alone, so the zero_grad() behind THAT one must fill again; and a step captured into a HIP graph
+	from a trainer that was running pipelined steps must contain its own zero fill (replays do not accumulate)."""
+	from vit_amd import dp, ops
+	ops.clear_grad_sinks()
+	g = torch.Generator().manual_seed(9)
+	x = torch.randn(16, 3, 16, 16, generator=g).to(gpu)
+	y = torch.randint(0, 10, (16,), generator=g).to(gpu)
+	model = _model(gpu)
+	tr = dp.Trainer(model, lr=0.0, weight_decay=0.0, pipelined_step=True)  # (parameters stay put: equal inputs give equal gradients)
+
+	def loss_fn(xi, yi):
+		with torch.autocast("cuda", dtype=torch.bfloat16):
+			return ops.cross_entropy(model(xi), yi)
+	tr.zero_grad()
+	loss_fn(x, y).backward()
+	tr.step()
+	assert tr.opt.grads_cleared
+	tr.pipelined_step = False
+	loss_fn(x, y).backward()  # (into the gradients the pipelined step cleared)
+	tr.wait_step()
+	once = tr.flat.grad.clone()
+	tr.step()
+	assert not tr.opt.grads_cleared and torch.equal(tr.flat.grad, once)  # the plain step leaves them
+	tr.zero_grad()
+	assert float(tr.flat.grad.abs().max()) == 0.0
+	# capture from a trainer in the middle of pipelined steps
+	tr.pipelined_step = True
+	loss_fn(x, y).backward()
+	tr.step()
+	gs = dp.GraphedStep(tr, loss_fn, [x, y])
+	assert not tr.pipelined_step
+	gs(x, y)
+	torch.cuda.synchronize()
+	first = tr.flat.grad.clone()
+	gs(x, y)
+	torch.cuda.synchronize()
+	assert float((tr.flat.grad - first).abs().max()) <= 1e-6 * float(first.abs().max())  # not twice the gradient
+	assert float((first - once).abs().max()) <= 1e-6 * float(once.abs().max())
+	gs.close()
+	tr.close()
+	ops.clear_grad_sinks()
+
+
+def test_forward_after_optimizer_steps_reads_the_updated_conv_stem(gpu):
+	"""The 7x7 conv embedding's weight (K = 147) is read through a K-padded bf16 copy that is cached between forward passes;
+	the fused optimizer rewrites the parameter without touching its version counter, so the cache must follow the
+	optimizer's own epoch: after two steps the model's forward must equal that of a fresh model holding the same
+	parameters (whose caches are empty)."""
+	from conftest import load_golden, relerr
+	from vit_amd import dp, ops
+	from vit_amd.layers import RMSNorm
+	from vit_amd.models import CvT
+	_, meta = load_golden("cvt_small_train")
+
+	def make():
+		class Cfg:
+			pass
+		for k, v in meta["config"].items():
+			setattr(Cfg, k, tuple(v) if isinstance(v, list) else v)
+		Cfg.norm = RMSNorm
+		Cfg.dropout = 0.0
+		torch.manual_seed(0)
+		return CvT(Cfg()).to(gpu).train()
+	g = torch.Generator().manual_seed(5)
+	x = torch.randn(8, 3, 32, 32, generator=g).to(gpu)
+	y = torch.randint(0, 10, (8,), generator=g).to(gpu)
+	ops.clear_grad_sinks()
+	model = make()
+	tr = dp.Trainer(model, lr=3e-2, weight_decay=0.0)
+	with torch.autocast("cuda", dtype=torch.bfloat16), torch.no_grad():
+		before = model(x).float()
+	for _ in range(2):
+		tr.zero_grad()
+		with torch.autocast("cuda", dtype=torch.bfloat16):
+			ops.cross_entropy(model(x), y).backward()
+		tr.step()
+	with torch.autocast("cuda", dtype=torch.bfloat16), torch.no_grad():
+		after = model(x).float()
+	sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+	tr.close()
+	ops.clear_grad_sinks()
+	fresh = make()
+	fresh.load_state_dict(sd)
+	ops.invalidate_casts()
+	with torch.autocast("cuda", dtype=torch.bfloat16), torch.no_grad():
+		want = fresh(x).float()
+	assert relerr(after, before) > 5e-2  # the steps did move the model
+	assert relerr(after, want) < 2e-2

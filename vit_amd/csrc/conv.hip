@@ -604,7 +604,7 @@ extern "C" int vitk_dwconv_bwd(const void* dy, const void* x, const void* w, voi
 	int64_t Ho, Wo;
 	VITK_REQUIRE(B > 0 && C > 0 && conv_geom(H, W, ks, stride, pad, &Ho, &Wo) && ks <= 5, VITK_ERR_SHAPE);
 	hipStream_t st = (hipStream_t)stream;
-	hipError_t e = hipMemsetAsync(dw, 0, (size_t)C * ks * ks * sizeof(float), st);
+	hipError_t e = vitk_zero_f32(dw, C * ks * ks, st);
 	if (e != hipSuccess) return VITK_ERR_HIP - (int)e;
 	DISPATCH_T(dtype, {
 		constexpr int V = VecOf<T>::N;
@@ -680,8 +680,8 @@ extern "C" int vitk_batchnorm_fwd(const void* x, const float* gamma, const float
 		});
 	}
 	VITK_REQUIRE(save_mean && save_rstd, VITK_ERR_NULL);
-	hipError_t e = hipMemsetAsync(save_mean, 0, (size_t)C * sizeof(float), st);
-	if (e == hipSuccess) e = hipMemsetAsync(save_rstd, 0, (size_t)C * sizeof(float), st);
+	hipError_t e = vitk_zero_f32(save_mean, C, st);
+	if (e == hipSuccess) e = vitk_zero_f32(save_rstd, C, st);
 	if (e != hipSuccess) return VITK_ERR_HIP - (int)e;
 	const dim3 cg = colgrid(rows, (int)C);
 	const unsigned fg = (unsigned)vitk_cdiv(C, 256);
@@ -713,8 +713,8 @@ extern "C" int vitk_batchnorm_bwd(const void* dy, const void* x, const float* ga
 	VITK_REQUIRE(rows > 0 && C > 0 && C < (1 << 30), VITK_ERR_SHAPE);
 	hipStream_t st = (hipStream_t)stream;
 	const int64_t n = rows * C;
-	hipError_t e = hipMemsetAsync(dgamma, 0, (size_t)C * sizeof(float), st);
-	if (e == hipSuccess) e = hipMemsetAsync(dbeta, 0, (size_t)C * sizeof(float), st);
+	hipError_t e = vitk_zero_f32(dgamma, C, st);
+	if (e == hipSuccess) e = vitk_zero_f32(dbeta, C, st);
 	if (e != hipSuccess) return VITK_ERR_HIP - (int)e;
 	const dim3 cg = colgrid(rows, (int)C);
 	DISPATCH_T(dtype, {

@@ -583,7 +583,7 @@ extern "C" int vitk_colsum(const void* x, float* out, int64_t M, int64_t N, int6
 	VITK_REQUIRE(M > 0 && N > 0 && ld >= N, VITK_ERR_SHAPE);
 	hipStream_t st = (hipStream_t)stream;
 	if (!accumulate) {
-		hipError_t e = hipMemsetAsync(out, 0, (size_t)N * sizeof(float), st);
+		hipError_t e = vitk_zero_f32(out, N, st);
 		if (e != hipSuccess) return VITK_ERR_HIP - (int)e;
 	}
 	DISPATCH_T(dtype, return launch_colsum<T>(x, out, M, N, ld, st));
@@ -656,7 +656,7 @@ extern "C" int vitk_batch_sum(const void* dx, float* dpos, int64_t B, int64_t ro
 	ysplit = vitk_cdiv(B, bchunk);
 	hipStream_t st = (hipStream_t)stream;
 	if (ysplit > 1 && !accumulate) {
-		hipError_t e = hipMemsetAsync(dpos, 0, (size_t)per * sizeof(float), st);
+		hipError_t e = vitk_zero_f32(dpos, per, st);
 		if (e != hipSuccess) return VITK_ERR_HIP - (int)e;
 	}
 	DISPATCH_T(dtype, {

@@ -503,7 +503,7 @@ int vitk_gemm_bf16_128(const vitk_gemm_desc& d, hipStream_t st, bool* colsum_don
 		}
 	}
 	if (a.splits > 1 && a.partials == nullptr && !d.accumulate) {
-		hipError_t e = hipMemset2DAsync(d.C, (size_t)d.ldc * sizeof(float), 0, (size_t)d.N * sizeof(float), (size_t)d.M, st);
+		hipError_t e = vitk_zero_f32_2d(reinterpret_cast<float*>(d.C), d.M, d.N, d.ldc, st);
 		if (e != hipSuccess) return VITK_ERR_HIP - (int)e;
 	}
 	static const bool no_dma = getenv("VITK_NO_DMA128") != nullptr;  // A-B switch

@@ -1005,7 +1005,7 @@ int vitk_gemm_bf16_256(const vitk_gemm_desc& d, hipStream_t st, bool* colsum_don
 		if (cs_fused) a.cs_partials = a.partials + need / (int64_t)sizeof(float);
 	}
 	if (a.splits > 1 && a.partials == nullptr && !d.accumulate) {
-		hipError_t e = hipMemset2DAsync(d.C, (size_t)d.ldc * sizeof(float), 0, (size_t)d.N * sizeof(float), (size_t)d.M, st);
+		hipError_t e = vitk_zero_f32_2d(reinterpret_cast<float*>(d.C), d.M, d.N, d.ldc, st);
 		if (e != hipSuccess) return VITK_ERR_HIP - (int)e;
 	}
 	int rc = VITK_ERR_UNSUPPORTED;

@@ -113,7 +113,7 @@ int vitk_gemm_generic(const vitk_gemm_desc& d, hipStream_t st) {
 		if (splits <= 1) { splits = 1; k_per_split = 0; }
 	}
 	if (splits > 1 && !d.accumulate) {
-		hipError_t e = hipMemset2DAsync(d.C, (size_t)d.ldc * sizeof(float), 0, (size_t)d.N * sizeof(float), (size_t)d.M, st);
+		hipError_t e = vitk_zero_f32_2d(reinterpret_cast<float*>(d.C), d.M, d.N, d.ldc, st);
 		if (e != hipSuccess) return VITK_ERR_HIP - (int)e;
 	}
 	dim3 grid((unsigned)vitk_cdiv(d.N, BN), (unsigned)vitk_cdiv(d.M, BM), (unsigned)splits);

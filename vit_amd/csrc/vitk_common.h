@@ -256,3 +256,25 @@ static inline int vitk_stream_grid(int64_t work_items, int block) {
 	if (g > 2048) g = 2048;
 	return (int)g;
 }
+
+// Zero fill of a small float buffer as a KERNEL.  (hipMemsetAsync captured into a HIP graph as a memset node was seen to
+// stop taking effect in replays that follow a hipStreamSynchronize / hipDeviceSynchronize on ROCm 7.0: accumulators that a
+// captured step clears this way -- BatchNorm statistics and gradients, depthwise-convolution weight gradients -- then keep
+// their values from replay to replay.  A kernel node does not have that problem.)
+static __global__ void vitk_zero_f32_kernel(float* __restrict__ p, int64_t n) {
+	for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = 0.f;
+}
+static inline hipError_t vitk_zero_f32(float* p, int64_t n, hipStream_t st) {
+	if (n <= 0) return hipSuccess;
+	hipLaunchKernelGGL(vitk_zero_f32_kernel, dim3(vitk_stream_grid(n, 256)), dim3(256), 0, st, p, n);
+	return hipGetLastError();
+}
+static __global__ void vitk_zero_f32_2d_kernel(float* __restrict__ p, int64_t rows, int64_t cols, int64_t ld) {
+	for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < rows * cols; i += (int64_t)gridDim.x * blockDim.x) p[(i / cols) * ld + i % cols] = 0.f;
+}
+// rows x cols floats with row stride ld (same reason as vitk_zero_f32)
+static inline hipError_t vitk_zero_f32_2d(float* p, int64_t rows, int64_t cols, int64_t ld, hipStream_t st) {
+	if (rows <= 0 || cols <= 0) return hipSuccess;
+	hipLaunchKernelGGL(vitk_zero_f32_2d_kernel, dim3(vitk_stream_grid(rows * cols, 256)), dim3(256), 0, st, p, rows, cols, ld);
+	return hipGetLastError();
+}

@@ -367,6 +367,7 @@ class FlatAdamW(torch.optim.Optimizer):
 		f = self.flat
 		if pipelined and self.shadow is not None and f.param.is_cuda and not torch.cuda.is_current_stream_capturing():
 			return self._step_pipelined(grad_scale)
+		self.grads_cleared = False  # (this form leaves the gradients as they are)
 		L.check(L.load().vitk_adamw_device_hparams(L.ptr(f.param), L.ptr(f.grad), L.ptr(self.m), L.ptr(self.v), L.ptr(self.wd_mask), L.ptr(self.shadow), f.numel,
 			L.ptr(self.hparams), L.ptr(self.step_state), grad_scale, L.stream()))
 		if self.shadow is None:
@@ -461,7 +462,11 @@ class GraphedStep:
 
 	def __init__(self, trainer, loss_fn, example_inputs, warmup=3):
 		assert not trainer.sync.active, "graph capture of the step is single-process (the all-reduce hooks are not captured)"
+		# a captured step is the plain sequence zero_grad -> forward -> backward -> optimizer on one stream: a pipelined step
+		# cannot be captured, and a warm-up step that cleared the gradients itself would leave the capture without its zero fill
 		trainer.wait_step()
+		trainer.pipelined_step = False
+		trainer.opt.grads_cleared = False
 		assert ops.GEMM_PROFILE is None, "no per-launch event timing inside a captured step"
 		self.trainer, self.loss_fn = trainer, loss_fn
 		self.inputs = [t.clone() for t in example_inputs]

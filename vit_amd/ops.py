@@ -145,7 +145,8 @@ def weight_padded(w, dtype, rows, cols, ld):
 	if ld == cols:
 		return weight_as(w, dtype).reshape(rows, cols)
 	_await_weight(w)
-	key = (w._version, dtype, w.data_ptr(), ld)
+	# (the fused optimizer rewrites the parameter without bumping its version counter: its epoch is part of the key)
+	key = (w._version, dtype, w.data_ptr(), ld, _weights_epoch)
 	hit = _cast_cache.get((id(w), "pad"))
 	if hit is not None and hit[0]() is w and hit[1] == key:
 		return hit[2]
