@@ -97,7 +97,16 @@ __global__ __launch_bounds__(256) void norm_fwd_kernel(const T* __restrict__ x, 
 	}
 }
 
-constexpr int BWD_THREADS = 768;  // 12 waves = 3 per SIMD (170 registers each), ONE workgroup per CU: every workgroup ends with a float atomic per column into dgamma / dbeta, and atomics from different XCDs on one address serialise at the memory side (768 workgroups spent 30 of 77 us there)
+// Backward: 8 waves per workgroup (two per SIMD, up to 256 registers each), ONE workgroup per CU.  Measured at 50,432 rows x 768
+// (bf16, + dres): 512 threads x 256 workgroups 70.5 us, 640 x 256 74.2, 768 x 256 76.7, 256 x 768 77.8, 384 x 512 85.4,
+// 512 x 512 88.3, 1024 x 256 185 (spills).  (More workgroups also mean more rows of column-sum partials to reduce.)
+#ifndef VITK_NORM_BWD_THREADS
+#define VITK_NORM_BWD_THREADS 512
+#endif
+#ifndef VITK_NORM_BWD_GRID
+#define VITK_NORM_BWD_GRID 256
+#endif
+constexpr int BWD_THREADS = VITK_NORM_BWD_THREADS;
 
 template <typename T, int VEC, int ITERS, bool RMS, int LPR>
 __global__ __launch_bounds__(BWD_THREADS) void norm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
@@ -417,7 +426,7 @@ int launch_fwd(const NormArgs& a, hipStream_t st) {
 }
 template <typename T, int VEC, int ITERS, bool RMS, int LPR = 64>
 int launch_bwd(const NormArgs& a, hipStream_t st) {
-	int grid = (int)std::min<int64_t>(vitk_cdiv(a.rows, (BWD_THREADS / 64) * (64 / LPR)), 256);
+	int grid = (int)std::min<int64_t>(vitk_cdiv(a.rows, (BWD_THREADS / 64) * (64 / LPR)), VITK_NORM_BWD_GRID);
 	size_t lds = (size_t)2 * a.d * sizeof(float);
 	float* partials = nullptr;
 	if (a.workspace != nullptr && vitk_aligned(a.workspace, 16) && a.workspace_bytes >= (int64_t)grid * 2 * a.d * (int64_t)sizeof(float))
