@@ -14,12 +14,42 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 
+import faulthandler  # noqa: E402
+faulthandler.dump_traceback_later(int(os.environ.get("STACKS_AFTER", "240")), exit=True)  # a hang names its place and ends the process
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 dev = torch.device("cuda", 0)
 torch.cuda.set_device(dev)
 dist.init_process_group("gloo")
 from vit_amd import dp, ops  # noqa: E402
 from vit_amd.models import ViT  # noqa: E402
+
+
+# gloo's own path for device tensors (pinned staging buffers filled and drained by asynchronous copies on streams of its
+# own, one per collective) stalls intermittently when two processes share one GPU: tools/diag/gloo_two_ranks_plain.py shows
+# it with stock torch modules alone.  The collectives here therefore stage through host memory themselves: the calling
+# stream is drained, the payload reduced (or broadcast) on the host, and copied back on the calling stream -- the order
+# in which the trainer issues them, and the streams it issues them on, are what this run checks.  GLOO_DEVICE_PATH=1
+# hands the device tensors to gloo as they are.
+if os.environ.get("GLOO_DEVICE_PATH", "0") == "0":
+	class _Done:
+		def wait(self, *a):
+			return True
+
+		def is_completed(self):
+			return True
+
+	def _staged(collective):
+		def call(t, *args, async_op=False, **kw):
+			if not t.is_cuda:
+				return collective(t, *args, async_op=async_op, **kw)
+			torch.cuda.current_stream().synchronize()
+			h = t.cpu()
+			collective(h, *args, **kw)
+			t.copy_(h)
+			return _Done() if async_op else None
+		return call
+
+	dist.all_reduce, dist.broadcast = _staged(dist.all_reduce), _staged(dist.broadcast)
 
 ops.WGRAD_OVERLAP_MIN_FLOPS = float(os.environ.get("MIN_FLOPS", "0"))  # every fused-block weight gradient on the second stream
 cfg = dict(bench.CONFIGS["vit_tiny"], n_block=4)
@@ -49,10 +79,13 @@ def run(sharded, pipelined):
 		x, y = xs[s], ys[s]
 		if sharded:
 			x, y = x[rank * per_rank:(rank + 1) * per_rank], y[rank * per_rank:(rank + 1) * per_rank]
+		state.update(trainer=trainer, step=(sharded, pipelined, s), stage="forward")
 		trainer.zero_grad()
 		with torch.autocast("cuda", dtype=torch.bfloat16):
 			loss = ops.cross_entropy(model(x.to(dev)), y.to(dev))
+		state["stage"] = "backward"
 		loss.backward()
+		state["stage"] = "step"
 		trainer.step()
 		losses.append(float(loss.detach()))
 	trainer.wait_step()
@@ -62,6 +95,28 @@ def run(sharded, pipelined):
 	return out
 
 
+state = {}
+
+
+def watchdog(after):
+	"""After `after` seconds without finishing: which collectives are outstanding and which streams still have work."""
+	import threading
+	import time
+
+	def body():
+		time.sleep(after)
+		t = state.get("trainer")
+		if t is None:
+			return
+		lane = ops.second_stream(dev)
+		print(f"[rank {rank}] step {state.get('step')} stage {state.get('stage')}: works completed {[w.is_completed() for w in t.sync.works]}, launched {t.sync.launched}, "
+			f"next bucket {t.sync.next_bucket} of {len(t.flat.buckets)}, main stream idle {torch.cuda.default_stream(dev).query()}, second stream idle {lane.stream.query()}, "
+			f"held {len(lane.held)} hooked {lane.hooked}", flush=True)
+	threading.Thread(target=body, daemon=True).start()
+
+
+if os.environ.get("WATCHDOG"):
+	watchdog(float(os.environ["WATCHDOG"]))
 ok = True
 for pipelined in (False, True):
 	p_dp, nb, _, l_dp = run(True, pipelined)
