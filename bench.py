@@ -143,6 +143,100 @@ def launcher_selftest(world, rank):
 	dist.destroy_process_group()
 
 
+def config_dict(name):
+	return CVT if name == "cvt" else (DEIT if name == "deit_tiny" else (COATNET if name == "coatnet" else CONFIGS[name]))
+
+
+def build_workload(name, dropout, dev, lr=1e-4, pipelined=True):
+	"""Model + trainer + loss closure of one named configuration on `dev`: (model, trainer, loss_of(x, y), teacher source)."""
+	from vit_amd import dp, ops
+	from vit_amd.models import ViT
+	c = config_dict(name)
+	torch.manual_seed(0)
+	teacher, tsrc = None, None
+	if name == "cvt":
+		from vit_amd.models import CvT
+		model = CvT(make_cvt_config(dropout)).to(dev)
+	elif name == "coatnet":
+		from vit_amd.layers import RMSNorm
+		from vit_amd.models import CoAtNet
+
+		class CoatCfg:
+			norm = RMSNorm
+		CoatCfg.dropout = dropout
+		for k_ in ("dims", "depths", "num_heads", "activation", "chw", "out_d"):
+			setattr(CoatCfg, k_, c[k_])
+		model = CoAtNet(CoatCfg()).to(dev)
+	elif name == "deit_tiny":
+		from vit_amd.models import DeiTViT
+		from vit_amd.models.teacher import frozen_teacher
+		model = DeiTViT(make_config(c, dropout)).to(dev)
+		# the teacher's weights: the reference's resnet20_cifar10 state_dict as recorded in the golden fixture (trained fc kept)
+		tsd, tsrc = None, "random init"
+		gpath = os.path.join(ROOT, "tests", "golden", "resnet20_teacher.npz")
+		if os.path.exists(gpath):
+			import numpy as np
+			z = np.load(gpath, allow_pickle=False)
+			tsd = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd/")}
+			tsrc = "reference resnet20_cifar10 weights (tests/golden/resnet20_teacher.npz)"
+		teacher = frozen_teacher(20, c["out_d"], tsd, fold_bn=True).to(dev).to(memory_format=torch.channels_last)
+	else:
+		model = ViT(make_config(c, dropout)).to(dev)
+	trainer = dp.Trainer(model, lr=lr, weight_decay=0.05, pipelined_step=pipelined)
+
+	def loss_of(xi, yi):
+		with torch.autocast("cuda", dtype=torch.bfloat16):
+			if teacher is not None:  # teacher forward under no_grad on stock PyTorch-ROCm, then the fused two-head loss
+				with torch.no_grad():
+					t_logits = teacher(xi.contiguous(memory_format=torch.channels_last))
+				cls, dist_ = model(xi)
+				return ops.deit_dual_loss(cls, dist_, yi, t_logits, alpha=c["alpha"], tau=c["tau"])
+			return ops.cross_entropy(model(xi), yi)
+	return model, trainer, loss_of, tsrc
+
+
+def time_secondary(name, dev, batch=0, dropout=0.0, steps=10, warmup=3, graph=False):
+	"""One further configuration timed in this process behind the headline: {config, per_gpu_batch, ms_per_step, value}."""
+	from vit_amd import dp, ops
+	c = config_dict(name)
+	batch = batch or c["batch"]
+	ops.clear_grad_sinks()
+	model, trainer, loss_of, _ = build_workload(name, dropout, dev, pipelined=not graph)
+	g = torch.Generator(device="cpu").manual_seed(1234)
+	x = torch.randn(batch, *c["chw"], generator=g).to(dev)
+	y = torch.randint(0, c["out_d"], (batch,), generator=g).to(dev)
+	graphed = None
+	if graph:
+		graphed = dp.GraphedStep(trainer, loss_of, [x, y], warmup=warmup)
+
+	def step():
+		if graphed is not None:
+			return graphed(x, y)
+		trainer.zero_grad()
+		loss = loss_of(x, y)
+		loss.backward()
+		trainer.step()
+		return loss
+	for _ in range(warmup):
+		step()
+	torch.cuda.synchronize()
+	t0 = time.perf_counter()
+	for _ in range(steps):
+		loss = step()
+	torch.cuda.synchronize()
+	el = time.perf_counter() - t0
+	final = loss.item()
+	trainer.wait_step()
+	if graphed is not None:
+		graphed.close()
+	trainer.close()
+	ops.clear_grad_sinks()
+	del model, trainer, x, y
+	torch.cuda.empty_cache()
+	return {"config": name, "per_gpu_batch": batch, "dropout": dropout, "hip_graph": graph, "steps": steps, "warmup": warmup, "ms_per_step": round(1e3 * el / steps, 3),
+		"value": round(batch * steps / el, 1), "unit": "images/sec", "final_loss": round(final, 4)}
+
+
 def main():
 	ap = argparse.ArgumentParser()
 	ap.add_argument("--gpus", type=int, default=1)
@@ -157,6 +251,7 @@ def main():
 	ap.add_argument("--full-last-block", action="store_true", help="ViT: run the last block on all token rows (default: only what the class-token row, the one row the head reads, depends on; same logits and gradients)")
 	ap.add_argument("--no-pipelined-step", action="store_true", help="finish the optimizer step before the next forward starts (default: it runs under it, on the second stream)")
 	ap.add_argument("--lr", type=float, default=1e-4)
+	ap.add_argument("--no-secondary", action="store_true", help="skip the other BASELINE configurations and the per-GPU batch sweep that a default one-GPU run times behind the headline")
 	ap.add_argument("--launcher-selftest", action="store_true", help=argparse.SUPPRESS)
 	args = ap.parse_args()
 
@@ -171,12 +266,17 @@ def main():
 		return launcher_selftest(world, rank)
 	torch.cuda.set_device(local_rank)
 	dev = torch.device("cuda", local_rank)
+	rccl_ranks = None
 	if world > 1:
 		os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 		dist.init_process_group("nccl", device_id=dev)
+		# how many ranks the collectives of this run really span: a sum of ones over RCCL, reported in the result line
+		ones = torch.ones(1, dtype=torch.float32, device=dev)
+		dist.all_reduce(ones)
+		rccl_ranks = int(ones.item())
+		assert rccl_ranks == world, f"RCCL all-reduce saw {rccl_ranks} ranks, WORLD_SIZE is {world}"
 
 	from vit_amd import dp, ops
-	from vit_amd.models import ViT
 	import vit_amd.models.vit as vit_model
 	if args.full_last_block:
 		vit_model.CLASS_ROWS_LAST_BLOCK = False
@@ -184,50 +284,12 @@ def main():
 	is_cvt = args.config == "cvt"
 	is_deit = args.config == "deit_tiny"
 	is_coat = args.config == "coatnet"
-	c = CVT if is_cvt else (DEIT if is_deit else (COATNET if is_coat else CONFIGS[args.config]))
+	c = config_dict(args.config)
 	batch = args.batch or c["batch"]
-	torch.manual_seed(0)
-	if is_cvt:
-		from vit_amd.models import CvT
-		model = CvT(make_cvt_config(args.dropout)).to(dev)
-	elif is_coat:
-		from vit_amd.layers import RMSNorm
-		from vit_amd.models import CoAtNet
-
-		class CoatCfg:
-			norm = RMSNorm
-			dropout = args.dropout
-		for k_ in ("dims", "depths", "num_heads", "activation", "chw", "out_d"):
-			setattr(CoatCfg, k_, c[k_])
-		model = CoAtNet(CoatCfg()).to(dev)
-	elif is_deit:
-		from vit_amd.models import DeiTViT
-		from vit_amd.models.teacher import frozen_teacher
-		model = DeiTViT(make_config(c, args.dropout)).to(dev)
-		# the teacher's weights: the reference's resnet20_cifar10 state_dict as recorded in the golden fixture (trained fc kept)
-		tsd, tsrc = None, "random init"
-		gpath = os.path.join(ROOT, "tests", "golden", "resnet20_teacher.npz")
-		if os.path.exists(gpath):
-			import numpy as np
-			z = np.load(gpath, allow_pickle=False)
-			tsd = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd/")}
-			tsrc = "reference resnet20_cifar10 weights (tests/golden/resnet20_teacher.npz)"
-		teacher = frozen_teacher(20, c["out_d"], tsd).to(dev).to(memory_format=torch.channels_last)
-	else:
-		model = ViT(make_config(c, args.dropout)).to(dev)
-	trainer = dp.Trainer(model, lr=args.lr, weight_decay=0.05, pipelined_step=not args.no_pipelined_step and not args.graph)
+	model, trainer, loss_of, tsrc = build_workload(args.config, args.dropout, dev, lr=args.lr, pipelined=not args.no_pipelined_step and not args.graph)
 	g = torch.Generator(device="cpu").manual_seed(1234 + rank)
 	x = torch.randn(batch, *c["chw"], generator=g).to(dev)
 	y = torch.randint(0, c["out_d"], (batch,), generator=g).to(dev)
-
-	def loss_of(xi, yi):
-		with torch.autocast("cuda", dtype=torch.bfloat16):
-			if is_deit:  # teacher forward under no_grad on stock PyTorch-ROCm, then the fused two-head loss
-				with torch.no_grad():
-					t_logits = teacher(xi.contiguous(memory_format=torch.channels_last))
-				cls, dist_ = model(xi)
-				return ops.deit_dual_loss(cls, dist_, yi, t_logits, alpha=c["alpha"], tau=c["tau"])
-			return ops.cross_entropy(model(xi), yi)
 
 	def step():
 		trainer.zero_grad()
@@ -288,9 +350,9 @@ def main():
 			"n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True,
 			"scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
 			"config": {"workload": "deit_tiny: ViT-Tiny/4 student with distillation token + head (d192/h3/L12/ff768, 66 tokens) distilled from a frozen CIFAR ResNet-20 "
-				f"teacher ({tsrc}; stock PyTorch-ROCm, no_grad), alpha {c['alpha']}, tau {c['tau']}, teacher fwd + student fwd + fused two-head loss + bwd + AdamW",
+				f"teacher ({tsrc}; eval BatchNorms folded into the convolutions; stock PyTorch-ROCm, no_grad), alpha {c['alpha']}, tau {c['tau']}, teacher fwd + student fwd + fused two-head loss + bwd + AdamW",
 				"global_batch": batch * world, "per_gpu_batch": batch, "parallelism": f"dp{world}", "hip_graph": bool(args.graph), "dropout": args.dropout},
-			"first_loss": None if first_loss is None else round(first_loss, 4), "final_loss": round(final_loss, 4), "lr": args.lr}), flush=True)
+			"first_loss": None if first_loss is None else round(first_loss, 4), "final_loss": round(final_loss, 4), "lr": args.lr, "rccl_ranks": rccl_ranks}), flush=True)
 	elif rank == 0 and is_coat:
 		print(json.dumps({"metric": "train images/sec (node) CoAtNet hybrid 224x224 bf16", "value": round(batch * world * args.steps / elapsed, 2), "unit": "images/sec",
 			"n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True,
@@ -298,7 +360,7 @@ def main():
 			"config": {"workload": "coatnet: conv stem + MBConv stages (112^2 x 64, 56^2 x 96, 28^2 x 192) + 3 transformer blocks on 784 tokens x 384 (32 heads of 12) + "
 				"5 on 196 tokens x 768 (32 heads of 24), SiLU, RMSNorm, 1000 classes, fwd+CE+bwd+AdamW; throughput only (the reference's class cannot be constructed)",
 				"global_batch": batch * world, "per_gpu_batch": batch, "parallelism": f"dp{world}", "hip_graph": bool(args.graph), "dropout": args.dropout},
-			"first_loss": None if first_loss is None else round(first_loss, 4), "final_loss": round(final_loss, 4), "lr": args.lr}), flush=True)
+			"first_loss": None if first_loss is None else round(first_loss, 4), "final_loss": round(final_loss, 4), "lr": args.lr, "rccl_ranks": rccl_ranks}), flush=True)
 	elif rank == 0 and is_cvt:
 		# secondary configuration (BASELINE config 3): throughput only, no FLOP model / roofline for it
 		print(json.dumps({"metric": "train images/sec (node) CvT-13 geometry 32x32 bf16", "value": round(batch * world * args.steps / elapsed, 2), "unit": "images/sec",
@@ -306,7 +368,7 @@ def main():
 			"scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
 			"config": {"workload": "cvt: CvTConfig defaults (64/192/384, depths 1/2/10, heads 1/3/6, silu, RMSNorm) at 32x32, 10 classes, fwd+CE+bwd+AdamW",
 				"global_batch": batch * world, "per_gpu_batch": batch, "parallelism": f"dp{world}", "hip_graph": bool(args.graph), "dropout": args.dropout},
-			"first_loss": None if first_loss is None else round(first_loss, 4), "final_loss": round(final_loss, 4), "lr": args.lr}), flush=True)
+			"first_loss": None if first_loss is None else round(first_loss, 4), "final_loss": round(final_loss, 4), "lr": args.lr, "rccl_ranks": rccl_ranks}), flush=True)
 	elif rank == 0:
 		value = batch * world * args.steps / elapsed
 		class_rows = vit_model.CLASS_ROWS_LAST_BLOCK and args.dropout == 0.0
@@ -360,6 +422,34 @@ def main():
 					if key == "whole run" and isinstance(rec, dict) and "derived_mfma_pipe_busy_frac" in rec:
 						out["roofline"]["mfma_pipe_busy_frac_whole_step_pmc"] = round(rec["derived_mfma_pipe_busy_frac"], 4)
 						out["roofline"]["mfma_pipe_busy_source"] = "profiles/r2_pmc_sq_counters.json"
+		if rccl_ranks is not None:
+			out["rccl_ranks"] = rccl_ranks  # ranks that a sum of ones over the RCCL process group counted
+		if world == 1 and args.config == "vit_b16" and not args.no_secondary and graphed is None and not args.batch and args.dropout == 0.0:
+			# behind the headline (whose fields above are final): the other BASELINE configurations and the headline model at
+			# the reference's default dropout, ~10 steps each, and the headline model over per-GPU batches (332: 256 tile rows,
+			# every GEMM of the step a whole number of rounds on 256 CUs)
+			trainer.wait_step()
+			trainer.close()
+			ops.clear_grad_sinks()
+			del model, trainer, x, y, loss, loss_of
+			torch.cuda.empty_cache()
+			secondary, sweep = [], []
+			runs = [("vit_tiny", dict()), ("vit_tiny", dict(graph=True)), ("deit_tiny", dict()), ("cvt", dict()), ("cvt", dict(graph=True)), ("coatnet", dict(steps=6)),
+				("vit_b16", dict(dropout=0.3, steps=6))]
+			for name, kw in runs:
+				try:
+					secondary.append(time_secondary(name, dev, **kw))
+				except Exception as e:  # the headline stands on its own
+					secondary.append({"config": name, **kw, "error": repr(e)[:200]})
+			for b in (64, 128, 332, 512):
+				try:
+					r = time_secondary("vit_b16", dev, batch=b, steps=6, warmup=2)
+					r["mfma_util_pct"] = round(100.0 * r["value"] * flops_img / (PEAK_BF16_TFLOPS * 1e12), 2)
+					sweep.append(r)
+				except Exception as e:
+					sweep.append({"config": "vit_b16", "per_gpu_batch": b, "error": repr(e)[:200]})
+			out["secondary"] = secondary
+			out["batch_sweep"] = sweep
 		if not args.no_cpu_baseline and world == 1:
 			out["cpu_baseline"] = cpu_baseline(c)
 		print(json.dumps(out), flush=True)

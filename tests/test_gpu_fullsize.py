@@ -85,3 +85,239 @@ def test_patchify_layer_is_bit_exact(gpu, name, dtype):
 	want = g["patches"].to(dtype)
 	assert got.shape == want.shape and got.dtype == dtype
 	assert torch.equal(got.cpu(), want)
+
+
+def _compare(model, logits, loss, xg, want, section, skip_zero_grads=False):
+	want_logits, want_loss, want_grads, want_gx = want
+	errs = {"logits": relerr(logits, want_logits), "loss": relerr(loss, want_loss), "grad_x": relerr(xg.grad, want_gx)}
+	gmax = max(float(v.abs().max()) for v in want_grads.values())
+	for k, p in model.named_parameters():
+		assert p.grad is not None, k
+		if skip_zero_grads and float(want_grads[k].abs().max()) < 1e-6 * gmax:
+			assert float(p.grad.abs().max()) < 1e-3 * gmax, k  # an exactly-zero gradient: rounding noise only
+			continue
+		errs["grad/" + k] = relerr(p.grad, want_grads[k])
+	_record(section, errs)
+	worst = max((k for k in errs if k.startswith("grad")), key=errs.get)
+	return errs, worst
+
+
+def test_vit_tiny_full_geometry_against_the_oracle(gpu):
+	"""BASELINE config 1 / 2 student at its own size: ViT-Tiny patch 4 on 32x32 (d 192, 3 heads, 12 blocks, d_ff 768, 65 tokens,
+	10 classes), batch 64, bf16 autocast against the float32 oracle."""
+	from oracle import vit_oracle as O
+	from vit_amd import ops
+	from vit_amd.layers import MHA
+	from vit_amd.models import ViT
+
+	class Cfg:
+		attention = MHA
+		norm = nn.LayerNorm
+		activation = "gelu"
+		use_layer_scale = False
+		use_qk_norm = False
+		dropout = 0.0
+		d_model, n_head, n_block, n_patch, d_ff, out_d, chw = 192, 3, 12, 8, 768, 10, (3, 32, 32)
+	B = 64
+	ops.clear_grad_sinks()
+	torch.manual_seed(0)
+	model = ViT(Cfg()).to(gpu)
+	g = torch.Generator().manual_seed(12)
+	x = torch.randn(B, 3, 32, 32, generator=g)
+	y = torch.randint(0, 10, (B,), generator=g)
+	xg = x.to(gpu).requires_grad_(True)
+	with torch.autocast("cuda", dtype=torch.bfloat16):
+		logits = model(xg)
+		loss = ops.cross_entropy(logits.float(), y.to(gpu))
+	loss.backward()
+	sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
+	want = O.loss_and_grads(lambda im, s: O.vit_fwd(im, s, 8, 12, 3, "layernorm", "gelu"), sd, x, y)
+	errs, worst = _compare(model, logits, loss, xg, want, "vit_tiny_batch64_bf16")
+	assert errs["logits"] < 2e-2 and errs["loss"] < 2e-2
+	assert errs[worst] < 2.5e-2 and errs["grad_x"] < 2.5e-2, (worst, errs[worst], errs["grad_x"])
+	assert (logits.float().argmax(-1).cpu() == want[0].argmax(-1)).float().mean() >= 0.9
+
+
+def test_cvt_baseline_geometry_against_the_oracle(gpu):
+	"""BASELINE config 3 at its own geometry: the reference's CvTConfig defaults (config.py:53-98 there: 64 / 192 / 384 wide,
+	depths 1 / 2 / 10, heads 1 / 3 / 6, SiLU, RMSNorm) on 32x32, batch 16, training mode, bf16 autocast against the float32
+	oracle.  Bars: the reference's own modules under bf16 autocast against their float32 run lose 0.7e-2 on the logits and
+	5.1e-2 on the worst gradient of the small CvT fixture (tests/golden/ref_bf16_errors.json)."""
+	import bench
+	from oracle import vit_oracle as O
+	from vit_amd import ops
+	from vit_amd.models import CvT
+	ops.clear_grad_sinks()
+	torch.manual_seed(0)
+	cfg = bench.make_cvt_config(0.0)
+	model = CvT(cfg).to(gpu).train()
+	with torch.no_grad():  # norm weights away from their zero init
+		for n, p in model.named_parameters():
+			if n.endswith("norm.weight") and p.dim() == 1 and "embedding" not in n:
+				p.add_(0.1 * torch.randn_like(p))
+	B = 16
+	g = torch.Generator().manual_seed(13)
+	x = torch.randn(B, 3, 32, 32, generator=g)
+	y = torch.randint(0, 10, (B,), generator=g)
+	sd = {k: v.detach().float().cpu().clone() for k, v in model.state_dict().items()}
+	xg = x.to(gpu).requires_grad_(True)
+	with torch.autocast("cuda", dtype=torch.bfloat16):
+		logits = model(xg)
+		loss = ops.cross_entropy(logits.float(), y.to(gpu))
+	loss.backward()
+	ocfg = {"chw": (3, 32, 32), "norm": "rmsnorm", "activation": "silu"}
+	for s_ in (1, 2, 3):
+		for f in ("emb_stride", "emb_pad", "depth", "heads", "qkv_stride"):
+			ocfg[f"s{s_}_{f}"] = getattr(cfg, f"s{s_}_{f}")
+	want = O.loss_and_grads(lambda im, s: O.cvt_fwd(im, s, ocfg, training=True), sd, x, y)
+	errs, worst = _compare(model, logits, loss, xg, want, "cvt_baseline_batch16_bf16", skip_zero_grads=True)
+	assert errs["logits"] < 3e-2 and errs["loss"] < 2e-2, (errs["logits"], errs["loss"])
+	assert errs[worst] < 6e-2 and errs["grad_x"] < 6e-2, (worst, errs[worst], errs["grad_x"])
+
+
+def test_coatnet_224_geometry_against_the_oracle(gpu):
+	"""BASELINE config 5 at its own geometry (dims 64/96/192/384/768, depths 2/2/3/5, 32 heads of 12 and 24, 224x224, 1000
+	classes), batch 2, training mode, bf16 autocast against the oracle's composition of the golden-pinned blocks (the model as
+	a whole is parity-unpinned: the reference's class cannot be constructed)."""
+	import bench
+	from oracle import vit_oracle as O
+	from vit_amd import ops
+	from vit_amd.layers import RMSNorm
+	from vit_amd.models import CoAtNet
+	c = bench.COATNET
+
+	class Cfg:
+		norm = RMSNorm
+		dropout = 0.0
+	for k_ in ("dims", "depths", "num_heads", "activation", "chw", "out_d"):
+		setattr(Cfg, k_, c[k_])
+	ops.clear_grad_sinks()
+	torch.manual_seed(0)
+	model = CoAtNet(Cfg()).to(gpu).train()
+	B = 2
+	g = torch.Generator().manual_seed(14)
+	x = torch.randn(B, 3, 224, 224, generator=g)
+	y = torch.randint(0, 1000, (B,), generator=g)
+	sd = {k: v.detach().float().cpu().clone() for k, v in model.state_dict().items()}
+	xg = x.to(gpu).requires_grad_(True)
+	with torch.autocast("cuda", dtype=torch.bfloat16):
+		logits = model(xg)
+		loss = ops.cross_entropy(logits.float(), y.to(gpu))
+	loss.backward()
+	ocfg = dict(dims=c["dims"], depths=c["depths"], num_heads=c["num_heads"], activation=c["activation"], norm="rmsnorm")
+	want = O.loss_and_grads(lambda im, s: O.coatnet_fwd(im, s, ocfg, training=True), sd, x, y)
+	errs, worst = _compare(model, logits, loss, xg, want, "coatnet_224_batch2_bf16", skip_zero_grads=True)
+	assert errs["logits"] < 3e-2 and errs["loss"] < 2e-2, (errs["logits"], errs["loss"])
+	assert errs[worst] < 8e-2 and errs["grad_x"] < 8e-2, (worst, errs[worst], errs["grad_x"])
+
+
+def test_deit_step_with_the_teacher_on_the_gpu(gpu):
+	"""BASELINE config 2 as bench.py runs it: the frozen ResNet-20 teacher (the reference's checkpoint weights, BatchNorms
+	folded, channels-last, bf16 autocast, stock PyTorch-ROCm) on the GPU against the reference teacher's recorded logits,
+	then the student step (distillation token, two heads, fused loss) on those teacher logits against the oracle."""
+	import bench
+	from oracle import vit_oracle as O
+	from vit_amd import ops
+	from vit_amd.models import DeiTViT
+	from vit_amd.models.teacher import frozen_teacher
+	from conftest import sub
+	g, meta = load_golden("resnet20_teacher")
+	tsd = sub(g, "sd")
+	xt = g["x"].to(gpu)
+	for fold in (False, True):
+		t = frozen_teacher(meta["depth"], meta["num_classes"], tsd, fold_bn=fold).to(gpu)
+		with torch.no_grad():
+			assert relerr(t(xt), g["logits"]) < 1e-4, fold  # float32 on the GPU
+		t = t.to(memory_format=torch.channels_last)
+		with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+			got = t(xt.contiguous(memory_format=torch.channels_last))
+		assert relerr(got, g["logits"]) < 2e-2, fold  # the form the benchmark runs
+	teacher = t
+	c = bench.DEIT
+	ops.clear_grad_sinks()
+	torch.manual_seed(1)
+	model = DeiTViT(bench.make_config(c)).to(gpu).train()
+	B = 32
+	gen = torch.Generator().manual_seed(15)
+	x = torch.randn(B, 3, 32, 32, generator=gen)
+	y = torch.randint(0, 10, (B,), generator=gen)
+	xg = x.to(gpu).requires_grad_(True)
+	with torch.autocast("cuda", dtype=torch.bfloat16):
+		with torch.no_grad():
+			t_logits = teacher(xg.detach().contiguous(memory_format=torch.channels_last))
+		cls, dist = model(xg)
+		loss = ops.deit_dual_loss(cls, dist, y.to(gpu), t_logits, alpha=c["alpha"], tau=c["tau"])
+	loss.backward()
+	sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
+	leaf = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+	xc = x.clone().requires_grad_(True)
+	wc, wd = O.deit_vit_fwd(xc, leaf, c["n_patch"], c["n_block"], c["n_head"], "layernorm", "gelu")
+	wl = O.deit_dual_loss_fwd(wc, wd, y, t_logits.float().cpu(), alpha=c["alpha"], tau=c["tau"])
+	wl.backward()
+	errs = {"cls": relerr(cls, wc), "dist": relerr(dist, wd), "loss": relerr(loss, wl), "grad_x": relerr(xg.grad, xc.grad)}
+	for k, p in model.named_parameters():
+		assert p.grad is not None, k
+		errs["grad/" + k] = relerr(p.grad, leaf[k].grad)
+	_record("deit_tiny_batch32_bf16", errs)
+	assert errs["cls"] < 2e-2 and errs["dist"] < 2e-2 and errs["loss"] < 2e-2
+	worst = max((k for k in errs if k.startswith("grad")), key=errs.get)
+	assert errs[worst] < 3e-2, (worst, errs[worst])
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_reference_shaped_glue_on_these_layers(gpu, dtype):
+	"""The reference's ViT.forward as it is written (models/vit.py:43-69 there) -- patchify, a stock nn.Linear mapper, the
+	per-sample Python loop that stacks class_token on top of each sample's tokens, pos_embed.repeat, the loop over blocks
+	unpacking (x, reg_loss), out[:, 0], a stock nn.Linear head -- restated here over vit_amd.layers, on the GPU, against the
+	golden the reference's own model produced (logits, loss, every parameter gradient)."""
+	from vit_amd import ops
+	from vit_amd.layers import MHA, ViTBlock
+	from vit_amd.layers.embeddings import patchify
+	from conftest import sub
+	g, meta = load_golden("vit_ln_gelu")
+	c = meta["config"]
+
+	class Cfg:
+		attention = MHA
+		norm = nn.LayerNorm
+		use_qk_norm = False
+		dropout = 0.0
+	for k, v in c.items():
+		if k not in ("norm", "batch"):
+			setattr(Cfg, k, tuple(v) if isinstance(v, list) else v)
+
+	class RefShapedViT(nn.Module):
+		def __init__(self, config):
+			super().__init__()
+			ch, h, w = config.chw
+			self.n_patch = config.n_patch
+			self.linear_mapper = nn.Linear(ch * (h // config.n_patch) * (w // config.n_patch), config.d_model)
+			self.class_token = nn.Parameter(torch.rand(1, config.d_model))
+			self.pos_embed = nn.Parameter(torch.randn(1, config.n_patch ** 2 + 1, config.d_model))
+			self.blocks = nn.ModuleList([ViTBlock(config) for _ in range(config.n_block)])
+			self.mlp = nn.Linear(config.d_model, config.out_d)
+
+		def forward(self, images):
+			n = images.shape[0]
+			tokens = self.linear_mapper(patchify(images, self.n_patch))
+			tokens = torch.stack([torch.vstack((self.class_token, tokens[i])) for i in range(len(tokens))])
+			out = tokens + self.pos_embed.repeat(n, 1, 1)
+			for block in self.blocks:
+				out, _ = block(out)
+			return self.mlp(out[:, 0])
+	ops.clear_grad_sinks()
+	model = RefShapedViT(Cfg()).to(gpu)
+	model.load_state_dict(sub(g, "sd"), strict=True)
+	x = g["x"].to(gpu).requires_grad_(True)
+	y = g["y"].to(gpu)
+	with torch.autocast("cuda", dtype=torch.bfloat16, enabled=dtype == torch.bfloat16):
+		logits = model(x)
+		loss = torch.nn.functional.cross_entropy(logits.float(), y)
+	loss.backward()
+	tol, gtol = (1e-4, 1e-4) if dtype == torch.float32 else (2e-2, 3e-2)
+	assert relerr(logits, g["logits"]) < tol and relerr(loss, g["loss"]) < tol
+	assert relerr(x.grad, g["grad_x"]) < gtol
+	for k, p in model.named_parameters():
+		assert p.grad is not None and relerr(p.grad, g["grad/" + k]) < gtol, k
+	if dtype == torch.float32:
+		assert torch.equal(logits.argmax(-1).cpu(), g["logits"].argmax(-1))

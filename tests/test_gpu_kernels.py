@@ -630,3 +630,22 @@ def test_ce_kd_loss_shapes(gpu, B, C):
 	l2.backward()
 	assert relerr(l2, O.cross_entropy_fwd(s0.double(), y, 0.1)) < 1e-4
 	assert relerr(s.grad, O.cross_entropy_bwd(s0.double(), y, 0.1)) < 1e-4
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,tokens,d,C", [(512, 66, 192, 10), (37, 5, 192, 10), (64, 199, 768, 1000), (3, 2, 1100, 7), (1, 2, 64, 1)])
+def test_dual_head_over_batch_slabs_and_classes(gpu, dtype, B, tokens, d, C):
+	"""Classifier on token row 0 and distillation head on token row 1 by one launch (models/vit.py:63-65 there, twice): few
+	classes spread the samples over many waves (10 classes at batch 512: slabs of 2 samples), 1000 classes keep a wave per
+	class over the whole batch; ragged last slab, d beyond the register-resident 1024 columns."""
+	import vit_amd._lib as L
+	x, xr = rnd((B, tokens, d), dtype, gpu, seed=1)
+	w0, w0r = rnd((C, d), dtype, gpu, scale=0.1, seed=2)
+	w1, w1r = rnd((C, d), dtype, gpu, scale=0.1, seed=3)
+	b0, b0r = rnd((C,), torch.float32, gpu, seed=4)
+	b1, b1r = rnd((C,), torch.float32, gpu, seed=5)
+	y0 = torch.full((B, C), 7.0, dtype=dtype, device=gpu)
+	y1 = torch.full((B, C), 7.0, dtype=dtype, device=gpu)
+	L.check(L.load().vitk_dual_head_fwd(L.ptr(x), L.ptr(w0), L.ptr(b0), L.ptr(w1), L.ptr(b1), L.ptr(y0), L.ptr(y1), B, tokens, d, C, L.dtype_code(dtype), L.stream()))
+	assert relerr(y0, xr[:, 0] @ w0r.t() + b0r) < TOL[dtype]
+	assert relerr(y1, xr[:, 1] @ w1r.t() + b1r) < TOL[dtype]

@@ -215,3 +215,9 @@ def test_teacher_resnet20_matches_the_reference_teacher():
 	with torch.no_grad():
 		assert relerr(m(g["x"]), g["logits"]) < TOL
 	assert not any(p.requires_grad for p in m.parameters()) and not m.training
+	# with its frozen BatchNorms folded into the convolutions (the form the distillation benchmark runs): same logits
+	f = frozen_teacher(meta["depth"], meta["num_classes"], sub(g, "sd"), fold_bn=True)
+	assert not any(isinstance(mod, torch.nn.BatchNorm2d) for mod in f.modules())
+	with torch.no_grad():
+		assert relerr(f(g["x"]), g["logits"]) < TOL
+	assert not any(p.requires_grad for p in f.parameters()) and not f.training

@@ -13,12 +13,11 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.gpu
-def test_two_ranks_on_one_gpu_stay_identical_and_follow_the_single_process_run():
+def _two_ranks(backend):
 	with socket.socket() as s:
 		s.bind(("127.0.0.1", 0))
 		port = s.getsockname()[1]
-	env = dict(os.environ, STACKS_AFTER="150", WATCHDOG="120")
+	env = dict(os.environ, STACKS_AFTER="150", WATCHDOG="120", BACKEND=backend, HSA_ENABLE_IPC_MODE_LEGACY="0")
 	cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
 		os.path.join(ROOT, "tools", "dp_two_ranks_one_gpu.py")]
 	r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=240)
@@ -26,4 +25,21 @@ def test_two_ranks_on_one_gpu_stay_identical_and_follow_the_single_process_run()
 	assert r.returncode == 0, tail
 	lines = r.stdout.splitlines()
 	assert "OK" in lines, tail
-	assert sum(1 for ln in lines if ln.startswith("pipelined_step=") and "replicas differ by 0.0e+00" in ln) == 2, tail
+	# plain and pipelined optimizer step, each without and with LayerScale
+	assert sum(1 for ln in lines if ln.startswith("pipelined_step=") and "replicas differ by 0.0e+00" in ln) == 4, tail
+
+
+@pytest.mark.gpu
+def test_two_ranks_on_one_gpu_stay_identical_and_follow_the_single_process_run():
+	_two_ranks("gloo")
+
+
+@pytest.mark.gpu
+def test_two_ranks_on_two_gpus_over_rccl():
+	"""The same run with one GPU per rank over torch.distributed "nccl" (RCCL): the collectives as dp.GradSync issues them
+	(asynchronous, on RCCL's stream, overlapping the backward and the second stream), no host staging.  Needs two GPUs;
+	device_count() does not initialise the GPU in this process."""
+	import torch
+	if torch.cuda.device_count() < 2:
+		pytest.skip("needs two GPUs")
+	_two_ranks("nccl")

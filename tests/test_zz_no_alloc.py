@@ -51,3 +51,9 @@ def test_noalloc_attention_backward_rejects_what_does_not_fit(gpu):
 	rc = lib.vitk_attention_bwd_noalloc(L.ptr(t), L.ptr(t), L.ptr(t), L.ptr(t), L.ptr(t), L.ptr(f), L.ptr(t), L.ptr(t), L.ptr(t),
 		B, H, S, S, dh, H * dh, H * dh, H * dh, H * dh, H * dh, H * dh, H * dh, 0.0, 0.0, 0, L.BF16, L.stream())
 	assert rc == -6 and b"scratch" in lib.vitk_strerror(rc)
+	# sizes whose product 2 * B * H * S overflows 64 bits are rejected as well, not wrapped into something that fits
+	big = (1 << 31) - 1
+	for Bx, Hx, Sx in ((big, big, big), (1 << 30, 1 << 30, 8), (big, 1, 1), (1, big, big)):
+		rc = lib.vitk_attention_bwd_noalloc(L.ptr(t), L.ptr(t), L.ptr(t), L.ptr(t), L.ptr(t), L.ptr(f), L.ptr(t), L.ptr(t), L.ptr(t),
+			Bx, Hx, Sx, Sx, dh, Hx * dh, Hx * dh, Hx * dh, Hx * dh, Hx * dh, Hx * dh, Hx * dh, 0.0, 0.0, 0, L.BF16, L.stream())
+		assert rc == -6, (Bx, Hx, Sx, rc)

@@ -121,6 +121,7 @@ def ref_bf16_errors(args):
 	from models.vit import ViT
 	ce = nn.CrossEntropyLoss()
 	out = {}
+	rel = lambda a, b: float(((a.detach().double() - b.double()).abs().max() / b.double().abs().max().clamp_min(1e-30)))
 	for name in ("vit_ln_gelu", "vit_p4_n65", "vit_rms_swiglu_ls", "vit_p16_geglu"):
 		z = np.load(os.path.join(args.out, name + ".npz"), allow_pickle=False)
 		c = json.loads(bytes(z["meta"]).decode())["config"]
@@ -144,7 +145,7 @@ def ref_bf16_errors(args):
 			logits = o[0] if isinstance(o, tuple) else o
 			loss = ce(logits.float(), y)
 		loss.backward()
-		rel = lambda a, b: float(((a.double() - b.double()).abs().max() / b.double().abs().max().clamp_min(1e-30)))
+		rel = lambda a, b: float(((a.detach().double() - b.double()).abs().max() / b.double().abs().max().clamp_min(1e-30)))
 		rec = {"logits": rel(logits, torch.from_numpy(z["logits"])), "grad_x": rel(x.grad, torch.from_numpy(z["grad_x"]))}
 		worst = ("", 0.0)
 		for k, p_ in model.named_parameters():
@@ -155,6 +156,73 @@ def ref_bf16_errors(args):
 		rec["worst_param_grad"] = {"name": worst[0], "err": worst[1]}
 		out[name] = rec
 		print(name, "logits", f"{rec['logits']:.3g}", "worst grad", worst)
+	# the modules with BatchNorm in them: CvT (three conv embeddings), ConvEmbedding alone, MBConv (three BatchNorms)
+	from config import CvTConfig
+	from layers.conv import MBConv
+	from layers.embeddings import ConvEmbedding
+	from models.cvt import CvT
+	for mode in ("train", "eval"):
+		z = np.load(os.path.join(args.out, f"cvt_small_{mode}.npz"), allow_pickle=False)
+		c = json.loads(bytes(z["meta"]).decode())["config"]
+
+		class CCfg(CvTConfig):
+			pass
+		for k, v in c.items():
+			if k not in ("norm", "batch"):
+				setattr(CCfg, k, tuple(v) if isinstance(v, list) else v)
+		CCfg.norm = RMSNorm
+		CCfg.dropout = 0.0
+		model = CvT(CCfg())
+		model.load_state_dict({k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd/")}, strict=True)
+		model.train(mode == "train")
+		x = torch.from_numpy(z["x"]).requires_grad_(True)
+		y = torch.from_numpy(z["y"])
+		with torch.autocast("cpu", dtype=torch.bfloat16):
+			logits = model(x)
+			loss = ce(logits.float(), y)
+		loss.backward()
+		rec = {"logits": rel(logits, torch.from_numpy(z["logits"])), "grad_x": rel(x.grad, torch.from_numpy(z["grad_x"]))}
+		worst = ("", 0.0)
+		gmax = max(float(np.abs(z[k]).max()) for k in z.files if k.startswith("grad/"))
+		for k, p_ in model.named_parameters():
+			if float(np.abs(z["grad/" + k]).max()) < 1e-6 * gmax:
+				continue  # an exactly-zero gradient in float32 (stage 3 attends to ONE key: its query projection receives none)
+			e = rel(p_.grad, torch.from_numpy(z["grad/" + k]))
+			rec["grad/" + k] = e
+			if e > worst[1]:
+				worst = (k, e)
+		rec["worst_param_grad"] = {"name": worst[0], "err": worst[1]}
+		out[f"cvt_small_{mode}"] = rec
+		print(f"cvt_small_{mode}", "logits", f"{rec['logits']:.3g}", "grad_x", f"{rec['grad_x']:.3g}", "worst grad", worst)
+
+	def leaf_module(tag, m, z, prefix):
+		m.load_state_dict({k[len(prefix) + 4:]: torch.from_numpy(z[k]) for k in z.files if k.startswith(prefix + "/sd/")}, strict=True)
+		x = torch.from_numpy(z[prefix + "/x"]).requires_grad_(True)
+		with torch.autocast("cpu", dtype=torch.bfloat16):
+			yv = m(x)
+		yv.backward(torch.from_numpy(z[prefix + "/dy"]).to(yv.dtype))
+		rec = {"y": rel(yv, torch.from_numpy(z[prefix + "/y"])), "dx": rel(x.grad, torch.from_numpy(z[prefix + "/dx"]))}
+		worst = ("", 0.0)
+		for k, p_ in m.named_parameters():
+			e = rel(p_.grad, torch.from_numpy(z[f"{prefix}/grad/{k}"]))
+			rec["grad/" + k] = e
+			if e > worst[1]:
+				worst = (k, e)
+		rec["worst_param_grad"] = {"name": worst[0], "err": worst[1]}
+		out[tag] = rec
+		print(tag, "y", f"{rec['y']:.3g}", "dx", f"{rec['dx']:.3g}", "worst grad", worst)
+	z = np.load(os.path.join(args.out, "conv_embedding.npz"), allow_pickle=False)
+	for nm, (ci, co, k, s_, p, hw) in json.loads(bytes(z["meta"]).decode())["cases"].items():
+		for mode in ("train", "eval"):
+			m = ConvEmbedding(ci, co, k, s_, p)
+			m.train(mode == "train")
+			leaf_module(f"conv_embedding/{nm}/{mode}", m, z, f"{nm}/{mode}")
+	z = np.load(os.path.join(args.out, "mbconv.npz"), allow_pickle=False)
+	for nm, (ci, co, stride, expand, act, hw) in json.loads(bytes(z["meta"]).decode())["cases"].items():
+		for mode in ("train", "eval"):
+			m = MBConv(ci, co, stride=stride, expand_ratio=expand, activation=act)
+			m.train(mode == "train")
+			leaf_module(f"mbconv/{nm}/{mode}", m, z, f"{nm}/{mode}")
 	with open(os.path.join(args.out, "ref_bf16_errors.json"), "w") as f:
 		json.dump({"what": "reference modules, torch.autocast('cpu', bfloat16) vs their float32 run; max|a-b|/max|b| per tensor", "torch": torch.__version__, "errors": out}, f, indent=1, sort_keys=True)
 

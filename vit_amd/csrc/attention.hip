@@ -115,7 +115,10 @@ extern "C" int vitk_attention_bwd_noalloc(const void* dout, const void* q, const
 	int64_t lddq, int64_t lddk, int64_t lddv, float scale, float dropout_p, uint64_t seed, int dtype, void* stream) {
 	VITK_REQUIRE(B > 0 && n_head > 0 && Sq > 0, VITK_ERR_SHAPE);
 	VITK_REQUIRE(B < (1ll << 31) && n_head < (1ll << 31) && Sq < (1ll << 31), VITK_ERR_SHAPE);
-	if (2 * B * n_head * Sq > STATIC_SCRATCH_FLOATS) return VITK_ERR_SCRATCH;
+	// 2 * B * n_head * Sq <= STATIC_SCRATCH_FLOATS, compared factor by factor (the product of three values below 2^31 does
+	// not fit in 64 bits)
+	constexpr int64_t CAP = STATIC_SCRATCH_FLOATS / 2;
+	if (B > CAP || n_head > CAP / B || Sq > CAP / (B * n_head)) return VITK_ERR_SCRATCH;
 	float* p = nullptr;
 	const int rc = static_scratch_ptr(&p);
 	if (rc != VITK_OK) return rc;

@@ -282,7 +282,7 @@ __global__ __launch_bounds__(256) void drop_cls_kernel(const T* __restrict__ x, 
 // reduces each dot product with shuffles.
 template <typename T>
 __global__ __launch_bounds__(256) void dual_head_kernel(const T* __restrict__ x, const T* __restrict__ w0, const float* __restrict__ b0, const T* __restrict__ w1,
-	const float* __restrict__ b1, T* __restrict__ y0, T* __restrict__ y1, int64_t B, int64_t tokens, int d, int C) {
+	const float* __restrict__ b1, T* __restrict__ y0, T* __restrict__ y1, int64_t B, int64_t tokens, int d, int C, int64_t samples_per_wave) {
 	const int lane = threadIdx.x & 63;
 	const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
 	if (c >= C) return;
@@ -294,7 +294,10 @@ __global__ __launch_bounds__(256) void dual_head_kernel(const T* __restrict__ x,
 	float wr[16];
 #pragma unroll
 	for (int i = 0; i < 16; ++i) wr[i] = lane + 64 * i < d ? to_f32<T>(w[lane + 64 * i]) : 0.f;
-	for (int64_t b = 0; b < B; ++b) {
+	// blockIdx.z: a slab of samples (with few classes the batch is what fills the chip; the weight row, d values, is cheap to re-read)
+	const int64_t b_begin = (int64_t)blockIdx.z * samples_per_wave;
+	const int64_t b_end = b_begin + samples_per_wave < B ? b_begin + samples_per_wave : B;
+	for (int64_t b = b_begin; b < b_end; ++b) {
 		const T* xr = x + (b * tokens + head) * d;
 		float acc = 0.f;
 #pragma unroll
@@ -737,9 +740,17 @@ extern "C" int vitk_dual_head_fwd(const void* x, const void* w_cls, const float*
 	int64_t B, int64_t tokens, int64_t d, int64_t C, int dtype, void* stream) {
 	VITK_REQUIRE(x && w_cls && w_dist && logits_cls && logits_dist, VITK_ERR_NULL);
 	VITK_REQUIRE(B > 0 && tokens >= 2 && d > 0 && C > 0 && d < (1ll << 31) && C < (1ll << 31), VITK_ERR_SHAPE);
+	// a wave per (head, class, slab of samples): about 8192 waves over the chip.  1000 classes: one slab (the weight matrix is
+	// read once, the kernel is bound by it); 10 classes at batch 512: 410 slabs of 2 samples (one slab took 569 us there, a
+	// chain of 512 dependent row reads per wave on 20 waves)
+	int64_t slabs = 8192 / (2 * C);
+	slabs = slabs < 1 ? 1 : (slabs > B ? B : slabs);
+	if (slabs > 65535) slabs = 65535;
+	const int64_t per = vitk_cdiv(B, slabs);
+	slabs = vitk_cdiv(B, per);
 	DISPATCH_T(dtype, {
-		hipLaunchKernelGGL((dual_head_kernel<T>), dim3((unsigned)vitk_cdiv(C, 4), 2), dim3(256), 0, (hipStream_t)stream, (const T*)x, (const T*)w_cls, b_cls, (const T*)w_dist, b_dist,
-			(T*)logits_cls, (T*)logits_dist, B, tokens, (int)d, (int)C);
+		hipLaunchKernelGGL((dual_head_kernel<T>), dim3((unsigned)vitk_cdiv(C, 4), 2, (unsigned)slabs), dim3(256), 0, (hipStream_t)stream, (const T*)x, (const T*)w_cls, b_cls, (const T*)w_dist, b_dist,
+			(T*)logits_cls, (T*)logits_dist, B, tokens, (int)d, (int)C, per);
 		VITK_CHECK_LAUNCH();
 		return VITK_OK;
 	});

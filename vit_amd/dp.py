@@ -112,10 +112,12 @@ class GradSync:
 		self.works = []
 		self.launched = []
 		self.hooks = [None] * len(flat.params)
+		self._cus_free_before = None
 		if self.active:
 			if flat.param.is_cuda:
-				# the persistent GEMMs leave the CUs they cannot fill a round with to the communication kernels
-				L.load().vitk_gemm_leave_cus_free(1)
+				# the persistent GEMMs leave the CUs they cannot fill a round with to the communication kernels (a process-wide
+				# option of the library: close() puts the previous value back)
+				self._cus_free_before = L.load().vitk_gemm_leave_cus_free(1)
 			for i, p in enumerate(flat.params):
 				self.hooks[i] = self._make_hook(i)
 				p.register_post_accumulate_grad_hook(self.hooks[i])
@@ -170,9 +172,29 @@ class GradSync:
 			self.next_bucket += 1
 
 	def _launch(self, b):
+		"""A collective is ordered behind the stream that is current where it is launched.  Weight-gradient products of the
+		backward pass may still be adding into this bucket on the second stream (ops.linear_wgrad(overlap=True); joined only
+		at the end of backward), and a hook that autograd fires itself -- a parameter whose gradient came back through
+		autograd's own accumulation: LayerScale, conv-embedding, MBConv, DyT parameters -- runs with the main stream current:
+		the launch then goes behind BOTH streams (arrivals reported by the sink-aware backward functions come here that way
+		already, through ops._sink_done)."""
 		start, end, _ = self.flat.buckets[b]
 		self.launched.append(b)
+		grad = self.flat.grad
+		lane = ops.lane_in_flight(grad.device) if grad.is_cuda else None
+		if lane is not None and L.stream() != lane.stream.cuda_stream:
+			lane.run_behind(self._all_reduce, start, end)
+		else:
+			self._all_reduce(start, end)
+
+	def _all_reduce(self, start, end):
 		self.works.append(dist.all_reduce(self.flat.grad[start:end], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+	def close(self):
+		"""Put the library's process-wide grid option back to what it was before this object set it."""
+		if self._cus_free_before is not None:
+			L.load().vitk_gemm_leave_cus_free(self._cus_free_before)
+			self._cus_free_before = None
 
 	def finish(self):
 		"""Wait for the collectives of this step (launching, in order, every bucket that has not gone out: the first
@@ -439,6 +461,7 @@ class Trainer:
 	def close(self):
 		"""Withdraw everything this trainer registered with ops (bf16 / transposed weight copies, gradient sinks)."""
 		self.opt.close()
+		self.sync.close()
 		for p in self.flat.params:
 			ops.unregister_grad_sink(p)
 

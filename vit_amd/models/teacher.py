@@ -54,12 +54,41 @@ class CifarResNet(nn.Module):
 		return self.fc(x.mean((2, 3)))
 
 
-def frozen_teacher(depth=20, num_classes=10, state_dict=None):
-	"""Teacher as DeiTTrainer holds it (deit_trainer.py:15-18 there): eval mode, no gradients."""
+def fold_batchnorms(model):
+	"""In place, for a teacher that stays in eval mode: every BatchNorm2d behind a bias-free convolution becomes part of
+	that convolution (w' = w * gamma / sqrt(var + eps) per output channel, b' = beta - mean * gamma / sqrt(var + eps), formed
+	in float64 and stored as float32), and the BatchNorm module is replaced by nn.Identity.  The function computed is the
+	same up to float32 rounding; the per-step BatchNorm kernels (a third of the distillation step's time at batch 512) are
+	gone.  After folding the module no longer has the reference's state_dict keys: load first, then fold."""
+	def fold(owner, conv_name, bn_name):
+		conv, bn = getattr(owner, conv_name), getattr(owner, bn_name)
+		assert isinstance(bn, nn.BatchNorm2d) and conv.bias is None and not bn.training
+		scale = bn.weight.double() / torch.sqrt(bn.running_var.double() + bn.eps)
+		w = (conv.weight.double() * scale.view(-1, 1, 1, 1)).float()
+		b = (bn.bias.double() - bn.running_mean.double() * scale).float()
+		new = nn.Conv2d(conv.in_channels, conv.out_channels, conv.kernel_size, conv.stride, conv.padding, bias=True).to(w.device)
+		new.weight = nn.Parameter(w, requires_grad=False)
+		new.bias = nn.Parameter(b, requires_grad=False)
+		setattr(owner, conv_name, new)
+		setattr(owner, bn_name, nn.Identity())
+	with torch.no_grad():
+		fold(model, "conv1", "bn1")
+		for stage in (model.layer1, model.layer2, model.layer3):
+			for blk in stage:
+				fold(blk, "conv1", "bn1")
+				fold(blk, "conv2", "bn2")
+	return model
+
+
+def frozen_teacher(depth=20, num_classes=10, state_dict=None, fold_bn=False):
+	"""Teacher as DeiTTrainer holds it (deit_trainer.py:15-18 there): eval mode, no gradients.  fold_bn: fold the (frozen)
+	BatchNorms into the convolutions in front of them (fold_batchnorms)."""
 	m = CifarResNet(depth, num_classes)
 	if state_dict is not None:
 		m.load_state_dict(state_dict, strict=True)
 	m.eval()
 	for p in m.parameters():
 		p.requires_grad_(False)
+	if fold_bn:
+		fold_batchnorms(m)
 	return m

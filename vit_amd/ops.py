@@ -78,9 +78,11 @@ def invalidate_casts():
 
 
 # Parameters that a pipelined optimizer step (dp.FlatAdamW.step(pipelined=True)) is still updating on the second stream:
-# id(param) -> [event behind the update of its piece, waited for already].  weight_as() is the one door through which the
-# kernels of this package reach a parameter (its float32 master, its bf16 copy, the transposed copy behind that), so the
-# wait lives there; one wait per piece (a marker packet on the stream costs a few microseconds).
+# id(param) -> [event behind the update of its piece, handles of the streams that wait for it already].  weight_as() is the
+# one door through which the kernels of this package reach a parameter (its float32 master, its bf16 copy, the transposed
+# copy behind that), so the wait lives there; one wait per piece AND stream (a marker packet on the stream costs a few
+# microseconds; a reader on another stream -- an evaluation or teacher forward on a side stream, a launch made while the
+# second stream is current -- must wait for itself).
 _pending_weights = {}
 _pending_lane = None
 
@@ -91,7 +93,7 @@ def set_pending_weights(pieces, lane):
 	for k in [k for k, rec in _pending_weights.items() if rec[1]]:  # (waited for already; records of another optimizer stay)
 		del _pending_weights[k]
 	for ev, params in pieces:
-		rec = [ev, False]
+		rec = [ev, set()]
 		for p in params:
 			_pending_weights[id(p)] = rec
 	_pending_lane = lane
@@ -109,9 +111,11 @@ def wait_pending_weights():
 def _await_weight(w):
 	if _pending_weights:
 		rec = _pending_weights.get(id(w))
-		if rec is not None and not rec[1]:
-			torch.cuda.current_stream().wait_event(rec[0])
-			rec[1] = True
+		if rec is not None:
+			sid = L.stream()
+			if sid not in rec[1]:
+				torch.cuda.current_stream().wait_event(rec[0])
+				rec[1].add(sid)
 
 
 def weight_as(w, dtype):
@@ -407,6 +411,13 @@ def second_stream(device):
 	if lane is None:
 		lane = _wgrad_lanes[device.index] = _WgradLane(device)
 	return lane
+
+
+def lane_in_flight(device):
+	"""The second stream of `device` if launches are in flight on it (weight-gradient products of the backward pass that is
+	running), else None."""
+	lane = _wgrad_lanes.get(device.index)
+	return lane if lane is not None and (lane.held or lane.hooked) else None
 
 
 def wgrad_sections():
