@@ -213,8 +213,9 @@ def test_coatnet_224_geometry_against_the_oracle(gpu):
 
 def test_deit_step_with_the_teacher_on_the_gpu(gpu):
 	"""BASELINE config 2 as bench.py runs it: the frozen ResNet-20 teacher (the reference's checkpoint weights, BatchNorms
-	folded, channels-last, bf16 autocast, stock PyTorch-ROCm) on the GPU against the reference teacher's recorded logits,
-	then the student step (distillation token, two heads, fused loss) on those teacher logits against the oracle."""
+	folded, float32 as in the reference, stock PyTorch-ROCm) on the GPU against the reference teacher's recorded logits,
+	then the student step (distillation token, two heads, fused loss) on those teacher logits against the oracle.  (Under
+	bf16 autocast MIOpen's teacher is 1.7e-2 ... 4.7e-2 off the reference's logits, tools/diag/teacher_variants.py: not used.)"""
 	import bench
 	from oracle import vit_oracle as O
 	from vit_amd import ops
@@ -225,14 +226,9 @@ def test_deit_step_with_the_teacher_on_the_gpu(gpu):
 	tsd = sub(g, "sd")
 	xt = g["x"].to(gpu)
 	for fold in (False, True):
-		t = frozen_teacher(meta["depth"], meta["num_classes"], tsd, fold_bn=fold).to(gpu)
+		teacher = frozen_teacher(meta["depth"], meta["num_classes"], tsd, fold_bn=fold).to(gpu)
 		with torch.no_grad():
-			assert relerr(t(xt), g["logits"]) < 1e-4, fold  # float32 on the GPU
-		t = t.to(memory_format=torch.channels_last)
-		with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
-			got = t(xt.contiguous(memory_format=torch.channels_last))
-		assert relerr(got, g["logits"]) < 2e-2, fold  # the form the benchmark runs
-	teacher = t
+			assert relerr(teacher(xt), g["logits"]) < 1e-4, fold  # float32 on the GPU; the folded form is what the benchmark runs
 	c = bench.DEIT
 	ops.clear_grad_sinks()
 	torch.manual_seed(1)
@@ -242,9 +238,9 @@ def test_deit_step_with_the_teacher_on_the_gpu(gpu):
 	x = torch.randn(B, 3, 32, 32, generator=gen)
 	y = torch.randint(0, 10, (B,), generator=gen)
 	xg = x.to(gpu).requires_grad_(True)
+	with torch.no_grad():
+		t_logits = teacher(xg.detach())
 	with torch.autocast("cuda", dtype=torch.bfloat16):
-		with torch.no_grad():
-			t_logits = teacher(xg.detach().contiguous(memory_format=torch.channels_last))
 		cls, dist = model(xg)
 		loss = ops.deit_dual_loss(cls, dist, y.to(gpu), t_logits, alpha=c["alpha"], tau=c["tau"])
 	loss.backward()
