@@ -195,6 +195,12 @@ int vitk_attention_bwd(const void* dout, const void* q, const void* k, const voi
 	int64_t B, int64_t n_head, int64_t Sq, int64_t Skv, int64_t dh,
 	int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t lddq, int64_t lddk, int64_t lddv,
 	float scale, float* scratch, int dtype, void* stream);
+/* The bf16 backward for head size 64, at most 224 keys and more than 32 (at most 256) queries runs as ONE kernel that forms
+ * the scores and their gradient once (five matrix products; `scratch` then only receives the stores of rows that do not
+ * exist); other shapes, and every shape after vitk_attention_bwd_one_pass(0), run as a dQ kernel followed by a dK/dV kernel
+ * that each recompute them (seven products).  Process-wide switch for comparisons (environment VITK_ATTN_BWD_FUSED=0 sets the
+ * initial value); returns the previous setting.  No counterpart in the reference (autograd of layers/attention.py:39-43). */
+int vitk_attention_bwd_one_pass(int on);
 /* The same with dropout on the attention probabilities: the `dropout_p` argument of
  * F.scaled_dot_product_attention in training mode (layers/attention.py:41,86):
  * out = (softmax(q k^T * scale) o M / (1 - p)) v with a keep mask M.  M is a pure function of

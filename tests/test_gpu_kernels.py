@@ -649,3 +649,63 @@ def test_dual_head_over_batch_slabs_and_classes(gpu, dtype, B, tokens, d, C):
 	L.check(L.load().vitk_dual_head_fwd(L.ptr(x), L.ptr(w0), L.ptr(b0), L.ptr(w1), L.ptr(b1), L.ptr(y0), L.ptr(y1), B, tokens, d, C, L.dtype_code(dtype), L.stream()))
 	assert relerr(y0, xr[:, 0] @ w0r.t() + b0r) < TOL[dtype]
 	assert relerr(y1, xr[:, 1] @ w1r.t() + b1r) < TOL[dtype]
+
+
+@pytest.mark.parametrize("B,h,Sq,Skv,p", [
+	(2, 2, 64, 64, 0.0), (2, 2, 65, 65, 0.0), (2, 3, 80, 80, 0.0), (1, 2, 96, 96, 0.0), (2, 2, 97, 97, 0.0), (1, 4, 128, 128, 0.0), (2, 12, 197, 197, 0.0),
+	(1, 2, 224, 224, 0.0), (1, 2, 256, 224, 0.0), (2, 2, 33, 17, 0.0), (2, 3, 256, 64, 0.0), (1, 2, 40, 1, 0.0), (3, 2, 197, 49, 0.0),
+	(64, 12, 197, 197, 0.0), (70, 12, 65, 65, 0.0),  # more (batch, head) pairs than CUs: a workgroup walks several (768: three, 840: three or four)
+	(2, 12, 197, 197, 0.3), (3, 2, 96, 80, 0.2), (70, 12, 65, 65, 0.3)])
+def test_attention_backward_in_one_pass(gpu, B, h, Sq, Skv, p):
+	"""The one-kernel backward (scores and their gradient formed once; key counts 64 ... 224 incl. the ragged 65 / 80 / 97 /
+	197, fewer keys than queries, one key, many pairs per workgroup, dropout) against the CPU oracle at the kernel bar AND
+	against the two-kernel form it replaces (same arithmetic per element, different summation orders: 3e-2 of the bf16
+	result's largest value)."""
+	from vit_amd import ops
+	import vit_amd._lib as L
+	dh, dtype = 64, torch.bfloat16
+	d = h * dh
+	seed = 0x0BAD_5EED + Sq
+	q, qr = rnd((B * Sq, d), dtype, gpu, seed=1)
+	k, kr = rnd((B * Skv, d), dtype, gpu, seed=2)
+	v, vr = rnd((B * Skv, d), dtype, gpu, seed=3)
+	do, dor = rnd((B * Sq, d), dtype, gpu, seed=4)
+	drop = (p, seed) if p > 0 else None
+	kw = dict(drop=drop) if drop else {}
+	out, lse = ops.attention_fwd(q, k, v, B, h, Sq, Skv, dh, **kw)
+	res = {}
+	lib = L.load()
+	was = lib.vitk_attention_bwd_one_pass(1)
+	try:
+		for mode in (1, 0):
+			lib.vitk_attention_bwd_one_pass(mode)
+			dq, dk, dv = torch.full_like(q, 7.0), torch.full_like(k, 7.0), torch.full_like(v, 7.0)
+			ops.attention_bwd(do, q, k, v, out, lse, dq, dk, dv, B, h, Sq, Skv, dh, **kw)
+			torch.cuda.synchronize()
+			res[mode] = (dq, dk, dv)
+	finally:
+		lib.vitk_attention_bwd_one_pass(was)
+	for a_, b_, name in zip(res[1], res[0], ("dq", "dk", "dv")):
+		assert torch.isfinite(a_.float()).all(), name
+		scale = float(b_.float().abs().max())
+		assert float((a_.float() - b_.float()).abs().max()) <= 3e-2 * scale + 1e-6, name
+	if B * h > 200:
+		return  # (the oracle comparison of the big cases would take minutes on the CPU; the two-kernel form is oracle-checked elsewhere)
+	q4 = O.split_heads(qr.reshape(B, Sq, d), h)
+	k4 = O.split_heads(kr.reshape(B, Skv, d), h)
+	v4 = O.split_heads(vr.reshape(B, Skv, d), h)
+	do4 = O.split_heads(dor.reshape(B, Sq, d), h)
+	if drop:
+		keep = O.attn_dropout_keep(seed, p, B, h, Sq, Skv)
+		o_ref, lse_ref = O.sdpa_dropout_fwd(q4, k4, v4, keep)
+		refs = O.sdpa_dropout_bwd(do4, q4, k4, v4, o_ref, lse_ref, keep)
+	else:
+		o_ref, lse_ref = O.sdpa_fwd(q4, k4, v4)
+		refs = O.sdpa_bwd(do4, q4, k4, v4, o_ref, lse_ref)
+	dq, dk, dv = res[1]
+	if Skv == 1:
+		assert dq.abs().max().item() < 5e-2 and dk.abs().max().item() < 5e-2
+	else:
+		assert relerr(dq, O.merge_heads(refs[0]).reshape(B * Sq, d)) < TOL[dtype]
+		assert relerr(dk, O.merge_heads(refs[1]).reshape(B * Skv, d)) < TOL[dtype]
+	assert relerr(dv, O.merge_heads(refs[2]).reshape(B * Skv, d)) < TOL[dtype]

@@ -12,12 +12,12 @@ cd /tmp && export TMPDIR=/tmp
 # main stream's kernels: their durations overlap), and of the same command with every kernel on one stream (each kernel's own
 # duration: what the bench line's roofline object, timed in its all-on-one-stream pass, is reconciled with; the optimizer
 # step not pipelined under the next forward either)
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $out/trace_overlap -o t -- python3 $root/bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-kernel-timing > $out/trace_overlap.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $out/trace_overlap -o t -- python3 $root/bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-secondary --no-kernel-timing > $out/trace_overlap.log 2>&1
 export VITK_WGRAD_OVERLAP=0
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $out/trace -o t -- python3 $root/bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-pipelined-step > $out/trace.log 2>&1
-timeout -s KILL 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/fetch -o f -- python3 $root/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-pipelined-step > $out/fetch.log 2>&1
-timeout -s KILL 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/write -o w -- python3 $root/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-pipelined-step > $out/write.log 2>&1
-timeout -s KILL 600 rocprofv3 --pmc SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY --output-format csv -d $out/sq -o s -- python3 $root/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-pipelined-step > $out/sq.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $out/trace -o t -- python3 $root/bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-secondary --no-pipelined-step > $out/trace.log 2>&1
+timeout -s KILL 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/fetch -o f -- python3 $root/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary --no-kernel-timing --no-pipelined-step > $out/fetch.log 2>&1
+timeout -s KILL 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/write -o w -- python3 $root/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary --no-kernel-timing --no-pipelined-step > $out/write.log 2>&1
+timeout -s KILL 600 rocprofv3 --pmc SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY --output-format csv -d $out/sq -o s -- python3 $root/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary --no-kernel-timing --no-pipelined-step > $out/sq.log 2>&1
 cd $root
 unset VITK_WGRAD_OVERLAP
 find $out -name "*counter_collection.csv" | head

@@ -61,6 +61,7 @@ SIGNATURES = {
 	"vitk_dyt_bwd": [P, P, P, P, P, P, P, P, I64, I64, I, P],
 	"vitk_attention_fwd": [P, P, P, P, P, I64, I64, I64, I64, I64, I64, I64, I64, I64, FL, I, P],
 	"vitk_attention_bwd": [P, P, P, P, P, P, P, P, P, I64, I64, I64, I64, I64, I64, I64, I64, I64, I64, I64, I64, FL, P, I, P],
+	"vitk_attention_bwd_one_pass": [I],
 	"vitk_attention_fwd_dropout": [P, P, P, P, P, I64, I64, I64, I64, I64, I64, I64, I64, I64, FL, FL, ctypes.c_uint64, I, P],
 	"vitk_attention_bwd_dropout": [P, P, P, P, P, P, P, P, P, I64, I64, I64, I64, I64, I64, I64, I64, I64, I64, I64, I64, FL, FL, ctypes.c_uint64, P, I, P],
 	"vitk_attention_bwd_noalloc": [P, P, P, P, P, P, P, P, P, I64, I64, I64, I64, I64, I64, I64, I64, I64, I64, I64, I64, FL, FL, ctypes.c_uint64, I, P],

@@ -48,6 +48,10 @@ int vitk_attention_generic(const AttnArgs& a, bool bwd, int dtype, hipStream_t s
 // bf16 MFMA kernels; return VITK_ERR_UNSUPPORTED when the shape does not qualify
 bool vitk_attention_mfma_ok(const AttnArgs& a, int dtype);
 int vitk_attention_mfma(const AttnArgs& a, bool bwd, hipStream_t st);
+// the backward of the above in one kernel (S and dP formed once): at most 224 keys, more than 32 queries; VITK_ATTN_BWD_FUSED=0
+// keeps the two-kernel form
+bool vitk_attention_bwd_fused_ok(const AttnArgs& a);
+int vitk_attention_bwd_fused(const AttnArgs& a, hipStream_t st);
 // bf16 MFMA kernels for any sequence length and head sizes 4, 8, ..., 64 (keys walked in blocks of 64, online softmax); no dropout
 bool vitk_attention_flash_ok(const AttnArgs& a, int dtype);
 int vitk_attention_flash(const AttnArgs& a, bool bwd, hipStream_t st);

@@ -673,6 +673,7 @@ bool vitk_attention_mfma_ok(const AttnArgs& a, int dtype) {
 int vitk_attention_mfma(const AttnArgs& a, bool bwd, hipStream_t st) {
 	if (!bwd) return run_fwd(a, st);
 	if (a.bwd_scratch == nullptr) return VITK_ERR_NULL;
+	if (vitk_attention_bwd_fused_ok(a)) return vitk_attention_bwd_fused(a, st);  // one pass: S and dP formed once
 	int rc = run_dq(a, st);  // also leaves lse (log2 units) and delta per query row in the scratch
 	if (rc != VITK_OK) return rc;
 	return run_dkv(a, st);
