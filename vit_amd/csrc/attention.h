@@ -19,6 +19,7 @@ struct AttnArgs {
 	const uint32_t* drop_epoch;  // device word mixed into the seed (see DropKey::epoch), or null
 	float* bwd_scratch;  // backward: [2][B * n_head * Sq] floats (lse in log2 units, delta = rowsum(dO o O)): dQ kernel -> dK/dV kernel
 	int heads_per_wg;  // set by the launcher: consecutive (batch, head) pairs one workgroup of the forward kernel walks
+	uint32_t dq_owner;  // one-pass backward, set by its launcher: wave (3 bits each) that forms dQ tile t = 4 * (16-query block) + (16-column block) of a step
 };
 
 // The dropout mask is a pure function of (seed, batch * n_head + head, query, key), so the forward and both backward
