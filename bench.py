@@ -147,7 +147,7 @@ def config_dict(name):
 	return CVT if name == "cvt" else (DEIT if name == "deit_tiny" else (COATNET if name == "coatnet" else CONFIGS[name]))
 
 
-def build_workload(name, dropout, dev, lr=1e-4, pipelined=True):
+def build_workload(name, dropout, dev, lr=1e-4, pipelined=True, bf16_buckets=False):
 	"""Model + trainer + loss closure of one named configuration on `dev`: (model, trainer, loss_of(x, y), teacher source)."""
 	from vit_amd import dp, ops
 	from vit_amd.models import ViT
@@ -182,7 +182,7 @@ def build_workload(name, dropout, dev, lr=1e-4, pipelined=True):
 		teacher = frozen_teacher(20, c["out_d"], tsd, fold_bn=True).to(dev)
 	else:
 		model = ViT(make_config(c, dropout)).to(dev)
-	trainer = dp.Trainer(model, lr=lr, weight_decay=0.05, pipelined_step=pipelined)
+	trainer = dp.Trainer(model, lr=lr, weight_decay=0.05, pipelined_step=pipelined, bf16_buckets=bf16_buckets)
 
 	def loss_of(xi, yi):
 		if teacher is not None:
@@ -255,6 +255,7 @@ def main():
 	ap.add_argument("--full-last-block", action="store_true", help="ViT: run the last block on all token rows (default: only what the class-token row, the one row the head reads, depends on; same logits and gradients)")
 	ap.add_argument("--no-pipelined-step", action="store_true", help="finish the optimizer step before the next forward starts (default: it runs under it, on the second stream)")
 	ap.add_argument("--lr", type=float, default=1e-4)
+	ap.add_argument("--bf16-buckets", action="store_true", help="N > 1: all-reduce the gradient buckets as bfloat16 (half the bytes on the links)")
 	ap.add_argument("--no-secondary", action="store_true", help="skip the other BASELINE configurations and the per-GPU batch sweep that a default one-GPU run times behind the headline")
 	ap.add_argument("--launcher-selftest", action="store_true", help=argparse.SUPPRESS)
 	args = ap.parse_args()
@@ -290,7 +291,7 @@ def main():
 	is_coat = args.config == "coatnet"
 	c = config_dict(args.config)
 	batch = args.batch or c["batch"]
-	model, trainer, loss_of, tsrc = build_workload(args.config, args.dropout, dev, lr=args.lr, pipelined=not args.no_pipelined_step and not args.graph)
+	model, trainer, loss_of, tsrc = build_workload(args.config, args.dropout, dev, lr=args.lr, pipelined=not args.no_pipelined_step and not args.graph, bf16_buckets=args.bf16_buckets)
 	g = torch.Generator(device="cpu").manual_seed(1234 + rank)
 	x = torch.randn(batch, *c["chw"], generator=g).to(dev)
 	y = torch.randint(0, c["out_d"], (batch,), generator=g).to(dev)
@@ -386,6 +387,7 @@ def main():
 			"config": {"workload": f"{args.config}: ViT d{c['d_model']}/h{c['n_head']}/L{c['n_block']}/ff{c['d_ff']} patch{c['chw'][1] // c['n_patch']} at {c['chw'][1]}x{c['chw'][2]}, "
 				f"{c['n_patch'] ** 2 + 1} tokens, fwd+CE+bwd+AdamW, fp32 master weights, bf16 activations", "global_batch": batch * world, "per_gpu_batch": batch,
 				"parallelism": f"dp{world}", "hip_graph": bool(args.graph), "dropout": args.dropout,
+				"gradient_buckets": "bf16" if args.bf16_buckets else "f32",
 				"last_block": "class rows only: the head reads out[:, 0], the last block computes what that row depends on (same logits and gradients as the full block; --full-last-block runs all rows)" if class_rows else "all token rows",
 				"optimizer_step": "runs under the next forward on the second stream" if not args.no_pipelined_step and not args.graph else "finished before the next forward"},
 			"train_gflop_per_image": round(flops_img / 1e9, 3),
@@ -430,8 +432,8 @@ def main():
 			out["rccl_ranks"] = rccl_ranks  # ranks that a sum of ones over the RCCL process group counted
 		if world == 1 and args.config == "vit_b16" and not args.no_secondary and graphed is None and not args.batch and args.dropout == 0.0:
 			# behind the headline (whose fields above are final): the other BASELINE configurations and the headline model at
-			# the reference's default dropout, ~10 steps each, and the headline model over per-GPU batches (332: 256 tile rows,
-			# every GEMM of the step a whole number of rounds on 256 CUs)
+			# the reference's default dropout, ~10 steps each, and the headline model over per-GPU batches (only multiples of 256
+			# images give whole 256-row tiles: 197 tokens per image is odd)
 			trainer.wait_step()
 			trainer.close()
 			ops.clear_grad_sinks()
@@ -445,7 +447,7 @@ def main():
 					secondary.append(time_secondary(name, dev, **kw))
 				except Exception as e:  # the headline stands on its own
 					secondary.append({"config": name, **kw, "error": repr(e)[:200]})
-			for b in (64, 128, 332, 512):
+			for b in (64, 128, 384, 512):
 				try:
 					r = time_secondary("vit_b16", dev, batch=b, steps=6, warmup=2)
 					r["mfma_util_pct"] = round(100.0 * r["value"] * flops_img / (PEAK_BF16_TFLOPS * 1e12), 2)

@@ -13,7 +13,7 @@ import torch.nn as nn
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port, bucket_bytes, ret):
+def _worker(rank, world, port, bucket_bytes, ret, bf16=False):
 	sys.path.insert(0, ROOT)
 	os.environ["MASTER_ADDR"] = "127.0.0.1"
 	os.environ["MASTER_PORT"] = str(port)
@@ -24,7 +24,7 @@ def _worker(rank, world, port, bucket_bytes, ret):
 	unused = nn.Linear(3, 3)  # never used in forward: its bucket must still be reduced (zeros)
 	model.add_module("unused", unused)
 	flat = dp.FlatModel(model, bucket_bytes=bucket_bytes)
-	sync = dp.GradSync(flat)
+	sync = dp.GradSync(flat, bf16_buckets=bf16)
 	g = torch.Generator().manual_seed(42)
 	x_all = torch.randn(8, 16, generator=g)
 	y_all = torch.randn(8, 4, generator=g)
@@ -48,20 +48,26 @@ def _worker(rank, world, port, bucket_bytes, ret):
 		i = flat.names.index(name)
 		o = flat.offsets[i]
 		got = results[-1][o:o + p.numel()].view(p.shape)
-		ok = ok and torch.allclose(got, p.grad, rtol=1e-5, atol=1e-6)
+		if bf16:  # each rank's share is rounded to bfloat16 (2^-9 relative) and the sum once more
+			ok = ok and float((got - p.grad).abs().max()) <= 1.5e-2 * float(p.grad.abs().max()) + 1e-6
+		else:
+			ok = ok and torch.allclose(got, p.grad, rtol=1e-5, atol=1e-6)
 	n_buckets = len(flat.buckets)
 	all_views = all(p.grad.data_ptr() == flat.grad.data_ptr() + 4 * o for p, o in zip(flat.params, flat.offsets))
 	ret[rank] = (ok, n_buckets, all_views, torch.equal(results[0], results[1]))
 	dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("bf16", [False, True])
 @pytest.mark.parametrize("bucket_bytes", [1 << 30, 2048, 64])
-def test_bucketed_allreduce_two_ranks(bucket_bytes):
+def test_bucketed_allreduce_two_ranks(bucket_bytes, bf16):
+	"""bf16: the buckets travel as bfloat16 (GradSync(bf16_buckets=True)); the float32 gradient that comes back is the
+	global-batch gradient to bfloat16 rounding."""
 	world = 2
-	port = 29500 + (os.getpid() % 1000) + {1 << 30: 0, 2048: 1, 64: 2}[bucket_bytes]
+	port = 29500 + (os.getpid() % 1000) + {1 << 30: 0, 2048: 1, 64: 2}[bucket_bytes] + (3 if bf16 else 0)
 	mgr = mp.Manager()
 	ret = mgr.dict()
-	mp.spawn(_worker, args=(world, port, bucket_bytes, ret), nprocs=world, join=True)
+	mp.spawn(_worker, args=(world, port, bucket_bytes, ret, bf16), nprocs=world, join=True)
 	assert len(ret) == world
 	for rank in range(world):
 		ok, n_buckets, all_views, same = ret[rank]

@@ -64,6 +64,7 @@ struct P8Args {
 	GemmDev g;
 	int tiles_m, tiles_n;
 	int vec8;  // epilogue operands / outputs may be accessed 16 bytes wide
+	int rows_per_xcd;  // tile order: whole tile rows per XCD instead of groups of four rows
 #ifdef VITK_P8_STAMPS
 	long long* stamps;
 #endif
@@ -98,6 +99,18 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_p8_kernel(P8Args a) {
 
 	// tile of this workgroup in a round: consecutive tiles (in grouped order) go to workgroups that share an XCD
 	auto tile_of = [&](int round, int64_t& m0, int64_t& n0) -> bool {
+		if (a.rows_per_xcd) {
+			// whole tile rows to one XCD (tile row r belongs to XCD r % 8, its tiles to consecutive workgroups of that XCD): an A
+			// panel is then fetched into ONE L2
+			const int per = nblk >> 3;  // workgroups of an XCD
+			const int rows_x = (a.tiles_m - xcd + 7) >> 3;  // tile rows of this XCD
+			const int t = round * per + idx;
+			if (t >= rows_x * a.tiles_n) return false;
+			const int rr = t / a.tiles_n;
+			m0 = (int64_t)(xcd + 8 * rr) * BM;
+			n0 = (int64_t)(t - rr * a.tiles_n) * BN;
+			return true;
+		}
 		const int base = round * nblk;
 		const int n = min(nblk, ntiles - base);
 		if (n <= 0) return false;
@@ -580,6 +593,14 @@ int vitk_gemm_bf16_p8(const vitk_gemm_desc& d, hipStream_t st) {
 #endif
 	if (!vitk_gemm_bf16_p8_ok(d)) return VITK_ERR_UNSUPPORTED;
 	a.vec8 = 1;
+	{
+		static int env = -1;
+		if (env < 0) {
+			const char* e = getenv("VITK_P8_ROWS_PER_XCD");
+			env = (e != nullptr && e[0] == '1') ? 1 : 0;
+		}
+		a.rows_per_xcd = env && (int64_t)a.tiles_m * a.tiles_n >= p8_blocks() && !p8_even_rounds();
+	}
 	switch (d.epilogue) {
 		case VITK_EPI_NONE: return launch_p8<VITK_EPI_NONE, -1>(a, st);
 		case VITK_EPI_ACT: return d.act == VITK_ACT_GELU ? launch_p8<VITK_EPI_ACT, VITK_ACT_GELU>(a, st) : launch_p8<VITK_EPI_ACT, -1>(a, st);
