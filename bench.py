@@ -310,8 +310,8 @@ def main():
 
 	graphed = None
 	if args.graph:
-		# the whole step as one HIP graph launch (single process): for launch-bound configurations (ViT-Tiny)
-		assert world == 1, "--graph is single-GPU"
+		# the whole step as one HIP graph launch: for launch-bound configurations (ViT-Tiny, CvT).  With more than one rank the
+		# graph holds forward + backward and the gradient all-reduces + optimizer step follow it eagerly (dp.GraphedStep)
 
 		graphed = dp.GraphedStep(trainer, loss_of, [x, y], warmup=max(args.warmup, 3))
 

@@ -528,3 +528,57 @@ def test_second_stream_orders_a_long_kernel_behind_run_behind_and_the_end_of_bac
 		assert float(seen["behind"][0]) == 1.0, (rep, "a launch made through run_behind ran ahead of the second stream")
 		assert float(seen["after"][0]) == 1.0, (rep, "the main stream read a result of the second stream before it was written")
 		assert float(out.float().abs().max()) > 0.0
+
+
+def test_graphed_step_with_gradient_sync_outside_the_graph(gpu, monkeypatch):
+	"""dp.GraphedStep on a trainer whose gradient synchronisation is active (more than one rank): the graph holds forward +
+	backward, the bucket all-reduces and the optimizer step run eagerly behind every replay.  The collective is replaced by
+	"two identical ranks" (the sum is twice the local gradient, the optimizer applies 1 / world), so the run must follow a
+	single-process captured run on the same data; every bucket is reduced once per step, in order, outside the capture."""
+	from vit_amd import dp, ops
+	g = torch.Generator().manual_seed(13)
+	xs = [torch.randn(16, 3, 16, 16, generator=g).to(gpu) for _ in range(4)]
+	ys = [torch.randint(0, 10, (16,), generator=g).to(gpu) for _ in range(4)]
+
+	def run(sharded):
+		ops.clear_grad_sinks()
+		calls = []
+		if sharded:
+			def fake_all_reduce(t, op=None, group=None, async_op=False):
+				assert not torch.cuda.is_current_stream_capturing()
+				calls.append(t.data_ptr())
+				t.mul_(2.0)
+				return _Done()
+			monkeypatch.setattr(dist, "is_initialized", lambda: True)
+			monkeypatch.setattr(dist, "get_world_size", lambda group=None: 2)
+			monkeypatch.setattr(dist, "broadcast", lambda *a, **k: None)
+			monkeypatch.setattr(dist, "all_reduce", fake_all_reduce)
+		model = _model(gpu)
+		tr = dp.Trainer(model, lr=1e-3, weight_decay=0.05, bucket_bytes=64 << 10)
+		assert tr.sync.active == sharded
+
+		def loss_fn(xi, yi):
+			with torch.autocast("cuda", dtype=torch.bfloat16):
+				return ops.cross_entropy(model(xi), yi)
+		gs = dp.GraphedStep(tr, loss_fn, [xs[0], ys[0]])
+		calls.clear()
+		losses = []
+		for x, y in zip(xs, ys):
+			losses.append(gs(x, y).clone())
+		torch.cuda.synchronize()
+		nb = len(tr.flat.buckets)
+		if sharded:
+			base = tr.flat.grad.data_ptr()
+			assert calls == [base + 4 * s for s, _, _ in tr.flat.buckets] * len(xs)
+			assert tr.opt.step_count == len(xs)
+		out = tr.flat.param.clone(), torch.stack(losses).cpu(), nb
+		gs.close()
+		tr.close()
+		monkeypatch.undo()
+		ops.clear_grad_sinks()
+		return out
+	p1, l1, _ = run(False)
+	p2, l2, nb = run(True)
+	assert nb > 1
+	assert float((l1 - l2).abs().max()) < 1e-3, (l1, l2)
+	assert float((p1 - p2).abs().max()) <= 1e-4 * float(p1.abs().max())

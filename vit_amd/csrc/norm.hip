@@ -99,7 +99,8 @@ __global__ __launch_bounds__(256) void norm_fwd_kernel(const T* __restrict__ x, 
 
 // Backward: 8 waves per workgroup (two per SIMD, up to 256 registers each), ONE workgroup per CU.  Measured at 50,432 rows x 768
 // (bf16, + dres): 512 threads x 256 workgroups 70.5 us, 640 x 256 74.2, 768 x 256 76.7, 256 x 768 77.8, 384 x 512 85.4,
-// 512 x 512 88.3, 1024 x 256 185 (spills).  (More workgroups also mean more rows of column-sum partials to reduce.)
+// 512 x 512 88.3, 1024 x 256 185 (spills).  (More workgroups also mean more rows of column-sum partials to reduce.)  A third
+// row of operands in flight per wave (below: two): 89 us at 512 x 256, 105 at 512 x 512, 178 at 768 x 256.
 #ifndef VITK_NORM_BWD_THREADS
 #define VITK_NORM_BWD_THREADS 512
 #endif

@@ -231,7 +231,7 @@ class GradSync:
 				w.wait()
 			if self.bf16_buckets:  # every bucket has been launched by now: the sums go back into the float32 gradient
 				_cast_into(self.stage, self.flat.grad)
-			if self.expected is None:
+			if self.expected is None and any(self.counts):  # (a step whose hooks were silenced teaches nothing)
 				self.expected = list(self.counts)
 		self.reset()
 
@@ -495,8 +495,8 @@ class GraphedStep:
 	(train.py:42-59) is eager and synchronises twice per step; this is the launch-free form of the same step.
 
 	`loss_fn(*inputs)` returns the scalar loss, or (loss, logits), and may only depend on its tensor arguments (their
-	shapes and dtypes are fixed at capture; new values are copied into the captured input buffers).  Single process only
-	(the gradient all-reduce hooks are not captured).  The warm-up steps that precede the capture (lazy one-time set-up
+	shapes and dtypes are fixed at capture; new values are copied into the captured input buffers).  With more than one rank
+	the graph holds forward + backward only and the gradient all-reduces and the optimizer step follow it eagerly.  The warm-up steps that precede the capture (lazy one-time set-up
 	must not happen while capturing) run on the example inputs and are then UNDONE: parameters, optimizer moments, step
 	count, module buffers (BatchNorm statistics) and the dropout seed counter are restored, so the first replay is the
 	first training step and the trajectory equals the eager one.  Learning rate and the other hyper-parameters are
@@ -506,7 +506,12 @@ class GraphedStep:
 	word stays registered on the device until close().  The returned tensors are overwritten by the next call."""
 
 	def __init__(self, trainer, loss_fn, example_inputs, warmup=3):
-		assert not trainer.sync.active, "graph capture of the step is single-process (the all-reduce hooks are not captured)"
+		# With gradient synchronisation active (more than one rank) the collectives stay OUTSIDE the graph: the captured part is
+		# zero_grad + forward + backward with the hooks silenced (GradSync.no_sync), and every call then launches the buckets'
+		# all-reduces and the optimizer step eagerly behind the replay -- a handful of launches instead of ~10^3, which is what
+		# the launch-bound 32x32 configurations need on every rank of a node (a ViT-Tiny / CvT gradient is 21 / 80 MB: the
+		# collectives cannot hide under a 1 ms backward anyway).
+		self.sharded = trainer.sync.active
 		# a captured step is the plain sequence zero_grad -> forward -> backward -> optimizer on one stream: a pipelined step
 		# cannot be captured, and a warm-up step that cleared the gradients itself would leave the capture without its zero fill
 		trainer.wait_step()
@@ -548,8 +553,14 @@ class GraphedStep:
 		self.trainer.zero_grad()
 		out = self.loss_fn(*self.inputs)
 		loss, logits = out if isinstance(out, tuple) else (out, None)
-		loss.backward()
-		self.trainer.step()
+		if self.sharded:
+			with self.trainer.no_sync():  # the hooks launch nothing: the collectives are issued by __call__, outside the graph
+				loss.backward()
+			if not torch.cuda.is_current_stream_capturing():
+				self.trainer.step()  # (warm-up steps: the eager tail, as every call runs it)
+		else:
+			loss.backward()
+			self.trainer.step()
 		return loss.detach() if logits is None else (loss.detach(), logits.detach())
 
 	def __call__(self, *inputs):
@@ -558,5 +569,8 @@ class GraphedStep:
 				dst.copy_(src, non_blocking=True)
 		self.trainer.opt.sync_hparams()
 		self.graph.replay()
-		self.trainer.opt.step_count += 1
+		if self.sharded:
+			self.trainer.step()  # every bucket's all-reduce (in order), the waits, the fused optimizer step: eager
+		else:
+			self.trainer.opt.step_count += 1
 		return self.loss if self.logits is None else (self.loss, self.logits)
