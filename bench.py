@@ -409,11 +409,11 @@ def main():
 			# HBM-side bytes per launch of that kernel: PMC counters cannot be read from inside this process; they come from
 			# separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same command (tools/pmc_traffic.py)
 			traffic, traffic_src = None, None
-			tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r2_pmc_hbm_traffic.json")
+			tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r3_pmc_hbm_traffic.json")
 			if args.config == "vit_b16" and os.path.exists(tpath):
 				rec = json.load(open(tpath)).get(label)
 				if rec:
-					traffic, traffic_src = round(rec["traffic_bytes_per_step"] * profiled_steps / n), "profiles/r2_pmc_hbm_traffic.json"
+					traffic, traffic_src = round(rec["traffic_bytes_per_step"] * profiled_steps / n), "profiles/r3_pmc_hbm_traffic.json"
 			out["roofline"] = {"bound": "mfma", "kernel": label, "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
 				"frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "launches": n, "avg_launch_ms": round(1e3 * sec / n, 4),
 				"gflop_per_launch": round(fl / n / 1e9, 2),
@@ -422,12 +422,12 @@ def main():
 				"all_gemm_kernels": {k: {"tflops": round(v[0] / v[1] / 1e12, 1), "ms_per_step": round(1e3 * v[1] / profiled_steps, 3), "launches_per_step": v[2] // profiled_steps} for k, v in agg.items()}}
 			# matrix-pipe busy fraction of the same workload from an SQ counter pass (SQ_VALU_MFMA_BUSY_CYCLES over
 			# 4 x SQ_BUSY_CU_CYCLES, i.e. against the clock the chip actually ran at): recorded, not measured in this run
-			spath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r2_pmc_sq_counters.json")
+			spath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r3_pmc_sq_counters.json")
 			if args.config == "vit_b16" and os.path.exists(spath):
 				for key, rec in json.load(open(spath)).items():
 					if key == "whole run" and isinstance(rec, dict) and "derived_mfma_pipe_busy_frac" in rec:
 						out["roofline"]["mfma_pipe_busy_frac_whole_step_pmc"] = round(rec["derived_mfma_pipe_busy_frac"], 4)
-						out["roofline"]["mfma_pipe_busy_source"] = "profiles/r2_pmc_sq_counters.json"
+						out["roofline"]["mfma_pipe_busy_source"] = "profiles/r3_pmc_sq_counters.json"
 		if rccl_ranks is not None:
 			out["rccl_ranks"] = rccl_ranks  # ranks that a sum of ones over the RCCL process group counted
 		if world == 1 and args.config == "vit_b16" and not args.no_secondary and graphed is None and not args.batch and args.dropout == 0.0:
