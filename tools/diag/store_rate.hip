@@ -45,6 +45,14 @@ __global__ __launch_bounds__(512) void k(char* out, int64_t ld, int tiles_n, int
 				uint4 val = {(unsigned)it, 1u, 2u, 3u};
 				*reinterpret_cast<uint4*>(base + row * ld + wn * 2 + c * 16) = val;
 			}
+		} else if (MODE == 6) {  // per-wave 128x64 sub-tile, 16 B per lane: a wave-instruction = 16 rows x 64 B (lanes row + 16 q)
+			const int wm = (wave >> 2) * 128, wn = (wave & 3) * 64;
+#pragma unroll
+			for (int it = 0; it < 16; ++it) {
+				const int row = wm + (it >> 1) * 16 + (lane & 15), c = (lane >> 4) + 4 * (it & 1);
+				uint4 val = {(unsigned)it, 1u, 2u, 3u};
+				*reinterpret_cast<uint4*>(base + row * ld + wn * 2 + c * 16) = val;
+			}
 		} else if (MODE == 4) {  // 16 B per lane, a wave-instruction = 4 rows x 256 B (half rows)
 #pragma unroll
 			for (int it = 0; it < 16; ++it) {
@@ -102,6 +110,7 @@ int main() {
 			run<3>("16B/lane rows, nontemporal", out, ld, tiles_n, blocks, same, stamps);
 			run<4>("16B/lane (4 rows x 256B)", out, ld, tiles_n, blocks, same, stamps);
 			run<5>("16B/lane per-wave (8 rows x 128B)", out, ld, tiles_n, blocks, same, stamps);
+			run<6>("16B/lane per-wave (16 rows x 64B)", out, ld, tiles_n, blocks, same, stamps);
 			run<1>("8B/lane fragments (16 rows x 32B)", out, ld, tiles_n, blocks, same, stamps);
 			run<2>("4B/lane (256B contiguous)", out, ld, tiles_n, blocks, same, stamps);
 		}
