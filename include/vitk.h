@@ -371,6 +371,14 @@ int vitk_dwconv_fwd(const void* x, const void* w, void* y, int64_t B, int64_t H,
 	int64_t ks, int64_t stride, int64_t pad, int dtype, void* stream);
 int vitk_dwconv_bwd(const void* dy, const void* x, const void* w, void* dx, float* dw, int64_t B, int64_t H, int64_t W, int64_t C,
 	int64_t ks, int64_t stride, int64_t pad, int dtype, void* stream);
+/* The same with row strides (in elements) for the INPUT-sized tensors: x rows are ldx apart, dx rows lddx apart, so that K and V
+ * (and their gradients) may be column slices of the joint q | k | v projection buffer of ConvAttention
+ * (layers/attention.py:57-64,73-78: three Linear layers on the same input, run here as one GEMM).  The output-sized
+ * tensors y and dy stay contiguous [B * Ho * Wo, C]. */
+int vitk_dwconv_fwd_ld(const void* x, int64_t ldx, const void* w, void* y, int64_t B, int64_t H, int64_t W, int64_t C,
+	int64_t ks, int64_t stride, int64_t pad, int dtype, void* stream);
+int vitk_dwconv_bwd_ld(const void* dy, const void* x, int64_t ldx, const void* w, void* dx, int64_t lddx, float* dw, int64_t B,
+	int64_t H, int64_t W, int64_t C, int64_t ks, int64_t stride, int64_t pad, int dtype, void* stream);
 /* im2col for the overlapping conv token embedding (layers/embeddings.py:21): x NCHW -> cols [B*Ho*Wo, C*ks*ks]
  * (the convolution itself is vitk_gemm on cols) and col2im (scatter-add) for its input gradient.
  * With tokens_in != 0 the input is token-major [B, H*W, C] (the layout CvT blocks produce), so the

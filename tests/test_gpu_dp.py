@@ -231,9 +231,18 @@ def test_module_by_module_functions_write_their_gradient_sinks(gpu):
 	tr = dp.Trainer(sunk)
 	tr.zero_grad()
 	backward(sunk)
-	for (k, p), o in zip(sunk.named_parameters(), tr.flat.offsets):
+	assert sorted(tr.flat.names) == sorted(k for k, _ in sunk.named_parameters())
+	for k, p, o in zip(tr.flat.names, tr.flat.params, tr.flat.offsets):
 		assert p.grad.data_ptr() == tr.flat.grad.data_ptr() + 4 * o, k  # still the view of the flat buffer
 		assert relerr(p.grad, want[k]) < 2e-3, k
+	# the three projections of a conv-attention module are ONE matrix in the flat buffers (q | k | v weights, then biases)
+	at = tr.flat.names.index("stage1_blocks.0.attn.q_proj.weight")
+	assert tr.flat.names[at:at + 8] == ["stage1_blocks.0.attn." + s for s in ("q_proj.weight", "k_proj.weight", "v_proj.weight", "q_proj.bias", "k_proj.bias",
+		"v_proj.bias", "conv_proj_k.weight", "conv_proj_v.weight")]
+	blk = sunk.stage1_blocks[0].attn
+	assert ops._joint([blk.q_proj.weight, blk.k_proj.weight, blk.v_proj.weight]) is not None
+	assert ops._joint([blk.q_proj.weight.grad, blk.k_proj.weight.grad, blk.v_proj.weight.grad]) is not None
+	assert [tr.flat.names[i] for i in tr.flat.module_order] == [k for k, _ in sunk.named_parameters()]
 	sunk.load_state_dict(plain.state_dict())  # BatchNorm statistics moved with the first forward
 	backward(sunk)  # no zero_grad: gradients accumulate, as .grad does
 	for k, p in sunk.named_parameters():

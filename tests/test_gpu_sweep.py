@@ -438,6 +438,42 @@ def test_conv_attention_many_rows(gpu, dtype, dim, heads, hw, stride, B):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("C,ks,stride,hw,B", [(64, 3, 1, 8, 5), (128, 3, 2, 7, 3), (20, 3, 1, 6, 4), (16, 5, 2, 9, 3)])
+def test_depthwise_conv_on_column_slices(gpu, dtype, C, ks, stride, hw, B):
+	"""vitk_dwconv_fwd_ld / vitk_dwconv_bwd_ld: the input and the input gradient as column slices of wider buffers (K | V of
+	the joint q | k | v projection) give bit for bit what the contiguous call gives, on the 16-byte-vector kernels and on
+	the element-wise ones (channels not a multiple of the vector width, 5 x 5 taps); columns outside the slice stay
+	untouched."""
+	from vit_amd import ops
+	g = torch.Generator().manual_seed(C + ks)
+	pad = ks // 2
+	rows = B * hw * hw
+	x = torch.randn(rows, C, generator=g).to(gpu).to(dtype)
+	w = (torch.randn(C, 1, ks, ks, generator=g) * 0.3).to(gpu).to(dtype)
+	wide = torch.full((rows, 3 * C), 7.0, dtype=dtype, device=gpu)
+	wide[:, C:2 * C] = x
+	y0, s0 = ops.dwconv_fwd(x, w, B, hw, hw, C, ks, stride, pad)
+	y1, s1 = ops.dwconv_fwd(wide[:, C:2 * C], w, B, hw, hw, C, ks, stride, pad)
+	assert s0 == s1 and torch.equal(y0, y1)
+	dy = torch.randn(y0.shape, generator=g).to(gpu).to(dtype)
+	dx0, dw0 = ops.dwconv_bwd(dy, x, w, B, hw, hw, C, ks, stride, pad)
+	dwide = torch.full((rows, 3 * C), 7.0, dtype=dtype, device=gpu)
+	dx1, dw1 = ops.dwconv_bwd(dy, wide[:, C:2 * C], w, B, hw, hw, C, ks, stride, pad, dx=dwide[:, C:2 * C])
+	assert torch.equal(dx0, dwide[:, C:2 * C]) and dx1.data_ptr() == dwide[:, C:2 * C].data_ptr()
+	assert relerr(dw1, dw0.double()) < 1e-5  # (float atomics: the order of the partial sums differs from launch to launch)
+	assert bool((dwide[:, :C] == 7.0).all()) and bool((dwide[:, 2 * C:] == 7.0).all())
+	# against the float64 convolution
+	xr = x.double().cpu().reshape(B, hw, hw, C).permute(0, 3, 1, 2).requires_grad_(True)
+	wr = w.double().cpu().requires_grad_(True)
+	yr = torch.nn.functional.conv2d(xr, wr, stride=stride, padding=pad, groups=C)
+	yr.backward(dy.double().cpu().reshape(B, yr.shape[2], yr.shape[3], C).permute(0, 3, 1, 2))
+	tol = 1e-5 if dtype == torch.float32 else 2e-2
+	assert relerr(y1, yr.detach().permute(0, 2, 3, 1).reshape(-1, C)) < tol
+	assert relerr(dwide[:, C:2 * C], xr.grad.permute(0, 2, 3, 1).reshape(-1, C)) < tol
+	assert relerr(dw1, wr.grad) < tol
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("ci,co,stride,expand,hw,B", [(32, 32, 1, 4, 28, 24), (64, 96, 2, 4, 28, 16), (24, 40, 2, 6, 15, 10)])
 def test_mbconv_many_rows(gpu, dtype, ci, co, stride, expand, hw, B):
 	"""MBConv (layers/conv.py:5-44 there) with SiLU at CoAtNet-like sizes (up to 19 k positions, 256 hidden channels, an

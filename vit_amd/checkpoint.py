@@ -17,8 +17,8 @@ from .dp import no_decay
 
 def _group_order(flat, decay_filter=no_decay):
 	"""Indices into flat.params in the order torch.optim.AdamW numbers them: decayed group, then undecayed group."""
-	dec = [i for i, n in enumerate(flat.names) if not decay_filter(n)]
-	nod = [i for i, n in enumerate(flat.names) if decay_filter(n)]
+	dec = [i for i in flat.module_order if not decay_filter(flat.names[i])]
+	nod = [i for i in flat.module_order if decay_filter(flat.names[i])]
 	return dec, nod
 
 

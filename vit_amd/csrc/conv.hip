@@ -12,7 +12,7 @@ namespace {
 // ---- depthwise conv ----------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void dwconv_fwd_kernel(const T* __restrict__ x, const T* __restrict__ w, T* __restrict__ y, int64_t B, int H, int W, int C,
-	int ks, int stride, int pad, int Ho, int Wo) {
+	int ks, int stride, int pad, int Ho, int Wo, int64_t ldx) {
 	const int64_t n = B * Ho * Wo * C;
 	for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
 		const int c = (int)(i % C);
@@ -28,7 +28,7 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(const T* __restrict__ x
 			for (int kw = 0; kw < ks; ++kw) {
 				const int ww = wo * stride - pad + kw;
 				if (ww < 0 || ww >= W) continue;
-				acc += to_f32<T>(x[((b * H + h) * W + ww) * C + c]) * to_f32<T>(w[(c * ks + kh) * ks + kw]);
+				acc += to_f32<T>(x[((b * H + h) * W + ww) * ldx + c]) * to_f32<T>(w[(c * ks + kh) * ks + kw]);
 			}
 		}
 		y[i] = from_f32<T>(acc);
@@ -37,7 +37,7 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(const T* __restrict__ x
 
 template <typename T>
 __global__ __launch_bounds__(256) void dwconv_bwd_dx_kernel(const T* __restrict__ dy, const T* __restrict__ w, T* __restrict__ dx, int64_t B, int H, int W,
-	int C, int ks, int stride, int pad, int Ho, int Wo) {
+	int C, int ks, int stride, int pad, int Ho, int Wo, int64_t lddx) {
 	const int64_t n = B * H * W * C;
 	for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
 		const int c = (int)(i % C);
@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void dwconv_bwd_dx_kernel(const T* __restrict_
 				acc += to_f32<T>(dy[((b * Ho + ho) * Wo + wo) * C + c]) * to_f32<T>(w[(c * ks + kh) * ks + kw]);
 			}
 		}
-		dx[i] = from_f32<T>(acc);
+		dx[(i / C) * lddx + c] = from_f32<T>(acc);
 	}
 }
 
@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256) void dwconv_bwd_dx_kernel(const T* __restrict_
 constexpr int DW_TY = 16;
 template <typename T>
 __global__ __launch_bounds__(64 * DW_TY) void dwconv_bwd_dw_kernel(const T* __restrict__ dy, const T* __restrict__ x, float* dw, int64_t B, int H, int W, int C, int ks,
-	int stride, int pad, int Ho, int Wo) {
+	int stride, int pad, int Ho, int Wo, int64_t ldx) {
 	__shared__ float red[DW_TY][25][64];
 	const int tx = threadIdx.x, ty = threadIdx.y;
 	const int c = blockIdx.x * 64 + tx;
@@ -89,7 +89,7 @@ __global__ __launch_bounds__(64 * DW_TY) void dwconv_bwd_dw_kernel(const T* __re
 				for (int kw = 0; kw < ks; ++kw) {
 					const int ww = wo * stride - pad + kw;
 					if (ww < 0 || ww >= W) continue;
-					acc[kh * ks + kw] += g * to_f32<T>(x[((b * H + h) * W + ww) * C + c]);
+					acc[kh * ks + kw] += g * to_f32<T>(x[((b * H + h) * W + ww) * ldx + c]);
 				}
 			}
 		}
@@ -122,7 +122,7 @@ __device__ __forceinline__ void load_taps3(const T* __restrict__ w, int c0, floa
 
 template <typename T, int V>
 __global__ __launch_bounds__(256) void dwconv3_fwd_kernel(const T* __restrict__ x, const T* __restrict__ w, T* __restrict__ y, int64_t B, int H, int W, int C,
-	int stride, int pad, int Ho, int Wo) {
+	int stride, int pad, int Ho, int Wo, int64_t ldx) {
 	const int ncg = C / V;
 	const int64_t n = B * Ho * ncg;
 	const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -133,7 +133,7 @@ __global__ __launch_bounds__(256) void dwconv3_fwd_kernel(const T* __restrict__ 
 	const int c0 = cg * V;
 	float wt[9][V];
 	load_taps3<T, V>(w, c0, wt);
-	const T* xb = x + b * H * W * C + c0;
+	const T* xb = x + b * H * W * ldx + c0;
 	T* yb = y + (b * Ho + ho) * (int64_t)Wo * C + c0;
 	for (int wo = 0; wo < Wo; ++wo) {
 		float acc[V];
@@ -148,7 +148,7 @@ __global__ __launch_bounds__(256) void dwconv3_fwd_kernel(const T* __restrict__ 
 				const int ww = wo * stride - pad + kw;
 				if (ww < 0 || ww >= W) continue;
 				float v[V];
-				load_vec<T, V>(xb + ((int64_t)h * W + ww) * C, v);
+				load_vec<T, V>(xb + ((int64_t)h * W + ww) * ldx, v);
 #pragma unroll
 				for (int j = 0; j < V; ++j) acc[j] += v[j] * wt[kh * 3 + kw][j];
 			}
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256) void dwconv3_fwd_kernel(const T* __restrict__ 
 
 template <typename T, int V>
 __global__ __launch_bounds__(256) void dwconv3_bwd_dx_kernel(const T* __restrict__ dy, const T* __restrict__ w, T* __restrict__ dx, int64_t B, int H, int W, int C,
-	int stride, int pad, int Ho, int Wo) {
+	int stride, int pad, int Ho, int Wo, int64_t lddx) {
 	const int ncg = C / V;
 	const int64_t n = B * H * ncg;
 	const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -178,7 +178,7 @@ __global__ __launch_bounds__(256) void dwconv3_bwd_dx_kernel(const T* __restrict
 		hos[kh] = (hn >= 0 && hn % stride == 0 && hn / stride < Ho) ? hn / stride : -1;
 	}
 	const T* gb = dy + b * Ho * Wo * C + c0;
-	T* db = dx + (b * H + h) * (int64_t)W * C + c0;
+	T* db = dx + (b * H + h) * (int64_t)W * lddx + c0;
 	for (int ww = 0; ww < W; ++ww) {
 		float acc[V];
 #pragma unroll
@@ -197,7 +197,7 @@ __global__ __launch_bounds__(256) void dwconv3_bwd_dx_kernel(const T* __restrict
 				for (int j = 0; j < V; ++j) acc[j] += v[j] * wt[kh * 3 + kw][j];
 			}
 		}
-		store_vec<T, V>(db + (int64_t)ww * C, acc);
+		store_vec<T, V>(db + (int64_t)ww * lddx, acc);
 	}
 }
 
@@ -206,7 +206,7 @@ __global__ __launch_bounds__(256) void dwconv3_bwd_dx_kernel(const T* __restrict
 // one float atomic per (channel, tap).
 template <typename T, int V>
 __global__ __launch_bounds__(256) void dwconv3_bwd_dw_kernel(const T* __restrict__ dy, const T* __restrict__ x, float* dw, int64_t B, int H, int W, int C, int stride,
-	int pad, int Ho, int Wo) {
+	int pad, int Ho, int Wo, int64_t ldx) {
 	__shared__ float red[32][8 * V + 1];
 	const int ncg = C / V;
 	const int cgl = threadIdx.x & 7, pl = threadIdx.x >> 3;
@@ -234,7 +234,7 @@ __global__ __launch_bounds__(256) void dwconv3_bwd_dw_kernel(const T* __restrict
 					const int ww = wo * stride - pad + kw;
 					if (ww < 0 || ww >= W) continue;
 					float v[V];
-					load_vec<T, V>(x + ((b * H + h) * W + ww) * C + c0, v);
+					load_vec<T, V>(x + ((b * H + h) * W + ww) * ldx + c0, v);
 #pragma unroll
 					for (int j = 0; j < V; ++j) acc[kh * 3 + kw][j] += g[j] * v[j];
 				}
@@ -578,21 +578,61 @@ static bool conv_geom(int64_t H, int64_t W, int64_t ks, int64_t stride, int64_t 
 	return *Ho > 0 && *Wo > 0;
 }
 
-extern "C" int vitk_dwconv_fwd(const void* x, const void* w, void* y, int64_t B, int64_t H, int64_t W, int64_t C, int64_t ks, int64_t stride, int64_t pad,
-	int dtype, void* stream) {
+// ldx / lddx: row stride (elements) of the INPUT-sized tensors x and dx, so that K and V may be column slices of a wider
+// buffer (the joint q | k | v projection of CvT's attention); the output-sized tensors y and dy are contiguous [*, C].
+extern "C" int vitk_dwconv_fwd_ld(const void* x, int64_t ldx, const void* w, void* y, int64_t B, int64_t H, int64_t W, int64_t C, int64_t ks, int64_t stride,
+	int64_t pad, int dtype, void* stream) {
 	VITK_REQUIRE(x && w && y, VITK_ERR_NULL);
 	int64_t Ho, Wo;
-	VITK_REQUIRE(B > 0 && C > 0 && conv_geom(H, W, ks, stride, pad, &Ho, &Wo), VITK_ERR_SHAPE);
+	VITK_REQUIRE(B > 0 && C > 0 && ldx >= C && conv_geom(H, W, ks, stride, pad, &Ho, &Wo), VITK_ERR_SHAPE);
 	DISPATCH_T(dtype, {
 		constexpr int V = VecOf<T>::N;
-		if (ks == 3 && C % V == 0 && vitk_aligned(x, 16) && vitk_aligned(y, 16)) {
+		if (ks == 3 && C % V == 0 && ldx % V == 0 && vitk_aligned(x, 16) && vitk_aligned(y, 16)) {
 			hipLaunchKernelGGL((dwconv3_fwd_kernel<T, V>), dim3((unsigned)vitk_cdiv(B * Ho * (C / V), 256)), dim3(256), 0, (hipStream_t)stream, (const T*)x, (const T*)w, (T*)y,
-				B, (int)H, (int)W, (int)C, (int)stride, (int)pad, (int)Ho, (int)Wo);
+				B, (int)H, (int)W, (int)C, (int)stride, (int)pad, (int)Ho, (int)Wo, ldx);
 			VITK_CHECK_LAUNCH();
 			return VITK_OK;
 		}
 		hipLaunchKernelGGL((dwconv_fwd_kernel<T>), dim3(vitk_stream_grid(B * Ho * Wo * C, 256)), dim3(256), 0, (hipStream_t)stream, (const T*)x, (const T*)w, (T*)y, B,
-			(int)H, (int)W, (int)C, (int)ks, (int)stride, (int)pad, (int)Ho, (int)Wo);
+			(int)H, (int)W, (int)C, (int)ks, (int)stride, (int)pad, (int)Ho, (int)Wo, ldx);
+		VITK_CHECK_LAUNCH();
+		return VITK_OK;
+	});
+}
+
+extern "C" int vitk_dwconv_fwd(const void* x, const void* w, void* y, int64_t B, int64_t H, int64_t W, int64_t C, int64_t ks, int64_t stride, int64_t pad,
+	int dtype, void* stream) {
+	return vitk_dwconv_fwd_ld(x, C, w, y, B, H, W, C, ks, stride, pad, dtype, stream);
+}
+
+extern "C" int vitk_dwconv_bwd_ld(const void* dy, const void* x, int64_t ldx, const void* w, void* dx, int64_t lddx, float* dw, int64_t B, int64_t H, int64_t W,
+	int64_t C, int64_t ks, int64_t stride, int64_t pad, int dtype, void* stream) {
+	VITK_REQUIRE(dy && x && w && dx && dw, VITK_ERR_NULL);
+	int64_t Ho, Wo;
+	VITK_REQUIRE(B > 0 && C > 0 && ldx >= C && lddx >= C && conv_geom(H, W, ks, stride, pad, &Ho, &Wo) && ks <= 5, VITK_ERR_SHAPE);
+	hipStream_t st = (hipStream_t)stream;
+	hipError_t e = vitk_zero_f32(dw, C * ks * ks, st);
+	if (e != hipSuccess) return VITK_ERR_HIP - (int)e;
+	DISPATCH_T(dtype, {
+		constexpr int V = VecOf<T>::N;
+		if (ks == 3 && C % V == 0 && ldx % V == 0 && lddx % V == 0 && vitk_aligned(x, 16) && vitk_aligned(dy, 16) && vitk_aligned(dx, 16)) {
+			hipLaunchKernelGGL((dwconv3_bwd_dx_kernel<T, V>), dim3((unsigned)vitk_cdiv(B * H * (C / V), 256)), dim3(256), 0, st, (const T*)dy, (const T*)w, (T*)dx, B, (int)H,
+				(int)W, (int)C, (int)stride, (int)pad, (int)Ho, (int)Wo, lddx);
+			VITK_CHECK_LAUNCH();
+			const unsigned gx = (unsigned)vitk_cdiv(C / V, 8);
+			const unsigned gy = (unsigned)std::max<int64_t>(1, std::min<int64_t>(vitk_cdiv(B * Ho * Wo, 4 * 32), std::max<int64_t>(1, 1024 / gx)));
+			hipLaunchKernelGGL((dwconv3_bwd_dw_kernel<T, V>), dim3(gx, gy), dim3(256), 0, st, (const T*)dy, (const T*)x, dw, B, (int)H, (int)W, (int)C, (int)stride, (int)pad,
+				(int)Ho, (int)Wo, ldx);
+			VITK_CHECK_LAUNCH();
+			return VITK_OK;
+		}
+		hipLaunchKernelGGL((dwconv_bwd_dx_kernel<T>), dim3(vitk_stream_grid(B * H * W * C, 256)), dim3(256), 0, st, (const T*)dy, (const T*)w, (T*)dx, B, (int)H, (int)W,
+			(int)C, (int)ks, (int)stride, (int)pad, (int)Ho, (int)Wo, lddx);
+		VITK_CHECK_LAUNCH();
+		const unsigned gx = (unsigned)vitk_cdiv(C, 64);
+		const unsigned gy = (unsigned)std::max<int64_t>(1, std::min<int64_t>(vitk_cdiv(B * Ho * Wo, 4 * DW_TY), std::max<int64_t>(1, 512 / gx)));
+		hipLaunchKernelGGL((dwconv_bwd_dw_kernel<T>), dim3(gx, gy), dim3(64, DW_TY), 0, st, (const T*)dy, (const T*)x, dw, B, (int)H, (int)W, (int)C, (int)ks, (int)stride,
+			(int)pad, (int)Ho, (int)Wo, ldx);
 		VITK_CHECK_LAUNCH();
 		return VITK_OK;
 	});
@@ -600,35 +640,7 @@ extern "C" int vitk_dwconv_fwd(const void* x, const void* w, void* y, int64_t B,
 
 extern "C" int vitk_dwconv_bwd(const void* dy, const void* x, const void* w, void* dx, float* dw, int64_t B, int64_t H, int64_t W, int64_t C, int64_t ks,
 	int64_t stride, int64_t pad, int dtype, void* stream) {
-	VITK_REQUIRE(dy && x && w && dx && dw, VITK_ERR_NULL);
-	int64_t Ho, Wo;
-	VITK_REQUIRE(B > 0 && C > 0 && conv_geom(H, W, ks, stride, pad, &Ho, &Wo) && ks <= 5, VITK_ERR_SHAPE);
-	hipStream_t st = (hipStream_t)stream;
-	hipError_t e = vitk_zero_f32(dw, C * ks * ks, st);
-	if (e != hipSuccess) return VITK_ERR_HIP - (int)e;
-	DISPATCH_T(dtype, {
-		constexpr int V = VecOf<T>::N;
-		if (ks == 3 && C % V == 0 && vitk_aligned(x, 16) && vitk_aligned(dy, 16) && vitk_aligned(dx, 16)) {
-			hipLaunchKernelGGL((dwconv3_bwd_dx_kernel<T, V>), dim3((unsigned)vitk_cdiv(B * H * (C / V), 256)), dim3(256), 0, st, (const T*)dy, (const T*)w, (T*)dx, B, (int)H,
-				(int)W, (int)C, (int)stride, (int)pad, (int)Ho, (int)Wo);
-			VITK_CHECK_LAUNCH();
-			const unsigned gx = (unsigned)vitk_cdiv(C / V, 8);
-			const unsigned gy = (unsigned)std::max<int64_t>(1, std::min<int64_t>(vitk_cdiv(B * Ho * Wo, 4 * 32), std::max<int64_t>(1, 1024 / gx)));
-			hipLaunchKernelGGL((dwconv3_bwd_dw_kernel<T, V>), dim3(gx, gy), dim3(256), 0, st, (const T*)dy, (const T*)x, dw, B, (int)H, (int)W, (int)C, (int)stride, (int)pad,
-				(int)Ho, (int)Wo);
-			VITK_CHECK_LAUNCH();
-			return VITK_OK;
-		}
-		hipLaunchKernelGGL((dwconv_bwd_dx_kernel<T>), dim3(vitk_stream_grid(B * H * W * C, 256)), dim3(256), 0, st, (const T*)dy, (const T*)w, (T*)dx, B, (int)H, (int)W,
-			(int)C, (int)ks, (int)stride, (int)pad, (int)Ho, (int)Wo);
-		VITK_CHECK_LAUNCH();
-		const unsigned gx = (unsigned)vitk_cdiv(C, 64);
-		const unsigned gy = (unsigned)std::max<int64_t>(1, std::min<int64_t>(vitk_cdiv(B * Ho * Wo, 4 * DW_TY), std::max<int64_t>(1, 512 / gx)));
-		hipLaunchKernelGGL((dwconv_bwd_dw_kernel<T>), dim3(gx, gy), dim3(64, DW_TY), 0, st, (const T*)dy, (const T*)x, dw, B, (int)H, (int)W, (int)C, (int)ks, (int)stride,
-			(int)pad, (int)Ho, (int)Wo);
-		VITK_CHECK_LAUNCH();
-		return VITK_OK;
-	});
+	return vitk_dwconv_bwd_ld(dy, x, C, w, dx, C, dw, B, H, W, C, ks, stride, pad, dtype, stream);
 }
 
 extern "C" int vitk_im2col(const void* x, void* cols, int64_t B, int64_t C, int64_t H, int64_t W, int64_t ks, int64_t stride, int64_t pad, int64_t ld_cols,

@@ -28,12 +28,39 @@ def no_decay(name):
 	return name.endswith("bias") or ("norm" in low) or ("layerscale" in low)
 
 
+def _joint_order(named):
+	"""Order of the parameters in the flat buffers: the module's own, except that the q / k / v projection weights of an
+	attention module that keeps three Linear layers on one input (layers.attention.ConvAttention; layers/attention.py:57-64
+	of the reference) follow one another, then their three biases, then its two depthwise convolution weights.  Each group is
+	then ONE matrix in the buffer (sizes that are multiples of 64 elements leave no padding between them), which is what lets
+	ops.ConvAttentionFn run the three projections as one GEMM on views of the parameters, of their bf16 copies and of their
+	gradient sinks."""
+	by_name = dict(named)
+	out, used = [], set()
+	for n, p in named:
+		if n in used:
+			continue
+		if n.endswith("q_proj.weight"):
+			base = n[:-len("q_proj.weight")]
+			group = [base + s for s in ("q_proj.weight", "k_proj.weight", "v_proj.weight", "q_proj.bias", "k_proj.bias", "v_proj.bias",
+				"conv_proj_k.weight", "conv_proj_v.weight")]
+			group = [g for g in group if g in by_name and g not in used]
+			out += [(g, by_name[g]) for g in group]
+			used.update(group)
+			continue
+		out.append((n, p))
+		used.add(n)
+	assert len(out) == len(named)
+	return out
+
+
 class FlatModel:
 	"""Moves a module's parameters into one flat float32 buffer (and their .grad into another)."""
 
 	def __init__(self, module, bucket_bytes=48 << 20):
 		self.module = module
-		named = [(n, p) for n, p in module.named_parameters() if p.requires_grad]
+		in_module_order = [(n, p) for n, p in module.named_parameters() if p.requires_grad]
+		named = _joint_order(in_module_order)
 		assert named, "no trainable parameters"
 		dev = named[0][1].device
 		assert all(p.dtype == torch.float32 and p.device == dev for _, p in named), "flat buffers hold float32 parameters on one device"
@@ -48,6 +75,10 @@ class FlatModel:
 		self.names = [n for n, _ in named]
 		self.params = [p for _, p in named]
 		self.offsets = offs
+		# indices into names / params / offsets in the module's own named_parameters() order (the order optimizers and
+		# checkpoints number parameters in)
+		where = {n: i for i, n in enumerate(self.names)}
+		self.module_order = [where[n] for n, _ in in_module_order]
 		for (n, p), o in zip(named, offs):
 			self.param[o:o + p.numel()].copy_(p.data.reshape(-1))
 			p.data = self.param[o:o + p.numel()].view(p.shape)
@@ -249,8 +280,8 @@ class FlatAdamW(torch.optim.Optimizer):
 
 	def __init__(self, flat, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, decay_filter=no_decay, bf16_shadow=True):
 		self.flat = flat
-		dec = [p for n, p in zip(flat.names, flat.params) if not decay_filter(n)]
-		nod = [p for n, p in zip(flat.names, flat.params) if decay_filter(n)]
+		dec = [flat.params[i] for i in flat.module_order if not decay_filter(flat.names[i])]
+		nod = [flat.params[i] for i in flat.module_order if decay_filter(flat.names[i])]
 		groups = [{"params": dec, "weight_decay": weight_decay}, {"params": nod, "weight_decay": 0.0}]
 		groups = [g for g in groups if g["params"]] or groups[:1]
 		super().__init__(groups, dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay))

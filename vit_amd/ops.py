@@ -1508,22 +1508,58 @@ def conv_embedding(mod, x, hw=None):
 
 
 def dwconv_fwd(x, w, Bn, H, W, C, ks, stride, pad):
+	"""Depthwise convolution of token-major x [Bn * H * W, C]; x may be a column slice of a wider buffer (row stride > C)."""
 	Ho, Wo = _conv_out(H, ks, stride, pad), _conv_out(W, ks, stride, pad)
+	assert x.stride(1) == 1 and x.shape == (Bn * H * W, C)
 	y = torch.empty((Bn * Ho * Wo, C), dtype=x.dtype, device=x.device)
-	L.check(L.load().vitk_dwconv_fwd(L.ptr(x), L.ptr(w), L.ptr(y), Bn, H, W, C, ks, stride, pad, L.dtype_code(x.dtype), L.stream()))
+	L.check(L.load().vitk_dwconv_fwd_ld(L.ptr(x), x.stride(0), L.ptr(w), L.ptr(y), Bn, H, W, C, ks, stride, pad, L.dtype_code(x.dtype), L.stream()))
 	return y, Ho * Wo
 
 
-def dwconv_bwd(dy, x, w, Bn, H, W, C, ks, stride, pad):
-	dx = torch.empty_like(x)
+def dwconv_bwd(dy, x, w, Bn, H, W, C, ks, stride, pad, dx=None):
+	"""(dx, dw) of dwconv_fwd; x and the optional output dx [Bn * H * W, C] may be column slices of wider buffers."""
+	assert x.stride(1) == 1 and dy.is_contiguous()
+	if dx is None:
+		dx = torch.empty((Bn * H * W, C), dtype=x.dtype, device=x.device)
+	assert dx.stride(1) == 1 and dx.shape == (Bn * H * W, C)
 	dw = torch.empty((C, 1, ks, ks), dtype=torch.float32, device=x.device)
-	L.check(L.load().vitk_dwconv_bwd(L.ptr(dy), L.ptr(x), L.ptr(w), L.ptr(dx), L.ptr(dw), Bn, H, W, C, ks, stride, pad, L.dtype_code(x.dtype), L.stream()))
+	L.check(L.load().vitk_dwconv_bwd_ld(L.ptr(dy), L.ptr(x), x.stride(0), L.ptr(w), L.ptr(dx), dx.stride(0), L.ptr(dw), Bn, H, W, C, ks, stride, pad,
+		L.dtype_code(x.dtype), L.stream()))
 	return dx, dw
+
+
+def _joint(ts):
+	"""The tensors stacked along their first dimension as ONE tensor without a copy, if they are equal-shaped, contiguous and
+	lie back to back inside one storage (parameters of a flat buffer laid out by dp.FlatModel, their bfloat16 copies and
+	their gradient sinks do); else None."""
+	if any(t is None for t in ts):
+		return None
+	t0 = ts[0]
+	step = t0.numel() * t0.element_size()
+	for i, t in enumerate(ts):
+		if t.shape != t0.shape or t.dtype != t0.dtype or not t.is_contiguous() or t.data_ptr() != t0.data_ptr() + i * step:
+			return None
+	if t0.untyped_storage().nbytes() < t0.storage_offset() * t0.element_size() + len(ts) * step:
+		return None  # neighbours by accident: separate allocations
+	return t0.as_strided((len(ts) * t0.shape[0],) + tuple(t0.shape[1:]), t0.stride())
+
+
+def _stacked(ts):
+	"""_joint(ts), or a stacked copy (one kernel) where the tensors are apart."""
+	j = _joint(ts)
+	return j if j is not None else torch.cat(ts, dim=0)
 
 
 class ConvAttentionFn(torch.autograd.Function):
 	"""CvT attention (layers/attention.py:67-93 of the reference): q/k/v Linear (with bias), depthwise conv on K and V
-	applied directly to token-major activations, attention with Skv <= Sq, output projection."""
+	applied directly to token-major activations, attention with Skv <= Sq, output projection.
+
+	The three projections read the same input, so they run as ONE GEMM against the stacked weight [3C, C] into a [tokens, 3C]
+	buffer whose column slices are q, k, v (the depthwise convolutions and the attention kernels take row strides); K and V
+	share ONE depthwise convolution over 2C channels; backward mirrors it: one weight-gradient GEMM, one input-gradient GEMM
+	with K = 3C.  Inside a dp.FlatModel the three weights (and biases, and convolution weights) are neighbours in the flat
+	buffers, so the stacked operands, their bf16 copies and their gradient sinks are views; elsewhere they are
+	concatenated (one small kernel each) and the gradients are handed to autograd as slices."""
 
 	@staticmethod
 	def forward(ctx, x, wq, bq, wk, bk, wv, bv, ck, cv, wo, bo, cfg):
@@ -1535,21 +1571,20 @@ class ConvAttentionFn(torch.autograd.Function):
 		assert S == H * W
 		dh = C // n_head
 		x2 = _flat(cast(x, dt))
-		q = linear_fwd(x2, weight_as(wq, dt), f32(bq))
-		k0 = linear_fwd(x2, weight_as(wk, dt), f32(bk))
-		v0 = linear_fwd(x2, weight_as(wv, dt), f32(bv))
-		ckc, cvc = weight_as(ck, dt), weight_as(cv, dt)
-		k1, Skv = dwconv_fwd(k0, ckc, Bn, H, W, C, ks, stride, pad)
-		v1, _ = dwconv_fwd(v0, cvc, Bn, H, W, C, ks, stride, pad)
-		o, lse = attention_fwd(q, k1, v1, Bn, n_head, S, Skv, dh, drop=drop)
+		wqkv = _stacked([weight_as(wq, dt), weight_as(wk, dt), weight_as(wv, dt)])
+		bqkv = _stacked([f32(bq), f32(bk), f32(bv)])
+		ckv = _stacked([weight_as(ck, dt), weight_as(cv, dt)])
+		qkv = linear_fwd(x2, wqkv, bqkv)  # [tokens, 3C]: q | k | v
+		kv1, Skv = dwconv_fwd(qkv[:, C:], ckv, Bn, H, W, 2 * C, ks, stride, pad)  # [Bn * Skv, 2C]: k | v
+		o, lse = attention_fwd(qkv[:, :C], kv1[:, :C], kv1[:, C:], Bn, n_head, S, Skv, dh, drop=drop)
 		y = linear_fwd(o, weight_as(wo, dt), f32(bo))
-		ctx.save_for_backward(x2, q, k0, v0, k1, v1, o, lse, wq, wk, wv, ck, cv, wo)
+		ctx.save_for_backward(x2, qkv, kv1, o, lse, wq, wk, wv, ck, cv, wo, wqkv, ckv)
 		ctx.meta = (x.shape, x.dtype, (bq, bk, bv, bo), cfg, dt, Skv)
 		return y.reshape(Bn, S, C)
 
 	@staticmethod
 	def backward(ctx, dy):
-		x2, q, k0, v0, k1, v1, o, lse, wq, wk, wv, ck, cv, wo = ctx.saved_tensors
+		x2, qkv, kv1, o, lse, wq, wk, wv, ck, cv, wo, wqkv, ckv = ctx.saved_tensors
 		(Bn, S, C), xdtype, (bq, bk, bv, bo), cfg, dt, Skv = ctx.meta
 		H, W, n_head, ks, stride, pad = cfg[:6]
 		drop = cfg[6] if len(cfg) > 6 else (0.0, 0)
@@ -1558,24 +1593,34 @@ class ConvAttentionFn(torch.autograd.Function):
 		sk = _Sinks(wq=wq, bq=bq, wk=wk, bk=bk, wv=wv, bv=bv, wo=wo, bo=bo)
 		dwo, dbo = linear_wgrad(dy2, o, bias_grad=True, dw_out=sk.buf("wo"), db_out=sk.buf("bo"))
 		do = linear_dgrad(dy2, weight_as(wo, dt))
-		dq, dk1, dv1 = torch.empty_like(q), torch.empty_like(k1), torch.empty_like(v1)
-		attention_bwd(do, q, k1, v1, o, lse, dq, dk1, dv1, Bn, n_head, S, Skv, dh, drop=drop)
-		dk0, dck = dwconv_bwd(dk1, k0, weight_as(ck, dt), Bn, H, W, C, ks, stride, pad)
-		dv0, dcv = dwconv_bwd(dv1, v0, weight_as(cv, dt), Bn, H, W, C, ks, stride, pad)
-		dwq, dbq = linear_wgrad(dq, x2, bias_grad=True, dw_out=sk.buf("wq"), db_out=sk.buf("bq"))
-		dwk, dbk = linear_wgrad(dk0, x2, bias_grad=True, dw_out=sk.buf("wk"), db_out=sk.buf("bk"))
-		dwv, dbv = linear_wgrad(dv0, x2, bias_grad=True, dw_out=sk.buf("wv"), db_out=sk.buf("bv"))
+		dqkv = torch.empty_like(qkv)
+		dkv1 = torch.empty_like(kv1)
+		attention_bwd(do, qkv[:, :C], kv1[:, :C], kv1[:, C:], o, lse, dqkv[:, :C], dkv1[:, :C], dkv1[:, C:], Bn, n_head, S, Skv, dh, drop=drop)
+		_, dckv = dwconv_bwd(dkv1, qkv[:, C:], ckv, Bn, H, W, 2 * C, ks, stride, pad, dx=dqkv[:, C:])
+		# the stacked weight / bias gradients go straight into the three neighbouring sinks where there are such; slices of
+		# a gradient whose sinks are apart (or absent) are added by hand (or handed to autograd)
+		w_sink = _joint([sk.buf("wq"), sk.buf("wk"), sk.buf("wv")])
+		b_sink = _joint([sk.buf("bq"), sk.buf("bk"), sk.buf("bv")])
+		dw3, db3 = linear_wgrad(dqkv, x2, bias_grad=True, dw_out=w_sink, db_out=b_sink)
+
+		def hand_out(names, joint_sink, g3):
+			out = []
+			for i, name in enumerate(names):
+				if joint_sink is None and sk.buf(name) is not None:
+					sk.buf(name).add_(g3[i * C:(i + 1) * C])
+				out.append(sk.ret(name, g3[i * C:(i + 1) * C]))
+			return out
+		gw = hand_out(("wq", "wk", "wv"), w_sink, dw3)
+		gb = hand_out(("bq", "bk", "bv"), b_sink, db3)
 		dx = None
 		if ctx.needs_input_grad[0]:
-			# dx = dq Wq + dk0 Wk + dv0 Wv: the second and third GEMM add onto the first through the residual epilogue (C aliases aux)
-			dx = linear_dgrad(dq, weight_as(wq, dt))
-			for g_, w_ in ((dk0, wk), (dv0, wv)):
-				gemm(g_, weight_as(w_, dt), dx, Bn * S, C, C, C, C, C, b_layout=L.MN_MAJOR, epilogue=L.EPI_RESIDUAL, aux=dx, ld_aux=C)
+			# dx = [dq | dk | dv] @ [Wq; Wk; Wv]: the weight as an MN-major operand (row n of the stacked weight is k-index n)
+			dx = torch.empty((Bn * S, C), dtype=dt, device=dy.device)
+			gemm(dqkv, wqkv, dx, Bn * S, C, 3 * C, 3 * C, C, C, b_layout=L.MN_MAJOR)
 			dx = dx.reshape(Bn, S, C)
 			if dx.dtype != xdtype:
 				dx = cast(dx, xdtype)
-		return (dx, sk.ret("wq", dwq), sk.ret("bq", dbq), sk.ret("wk", dwk), sk.ret("bk", dbk), sk.ret("wv", dwv), sk.ret("bv", dbv),
-			grad_as(dck, ck), grad_as(dcv, cv), sk.ret("wo", dwo), sk.ret("bo", dbo), None)
+		return (dx, gw[0], gb[0], gw[1], gb[1], gw[2], gb[2], grad_as(dckv[:C], ck), grad_as(dckv[C:], cv), sk.ret("wo", dwo), sk.ret("bo", dbo), None)
 
 
 class MBConvFn(torch.autograd.Function):
