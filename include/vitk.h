@@ -400,6 +400,17 @@ int vitk_batchnorm_fwd(const void* x, const float* gamma, const float* beta, flo
 	void* y, float* save_mean, float* save_rstd, int64_t rows, int64_t C, float eps, float momentum, int training, int dtype, void* stream);
 int vitk_batchnorm_bwd(const void* dy, const void* x, const float* gamma, const float* save_mean, const float* save_rstd,
 	void* dx, float* dgamma, float* dbeta, int64_t rows, int64_t C, int training, int dtype, void* stream);
+/* The same with a caller-provided scratch buffer (16-byte aligned, vitk_batchnorm_workspace_bytes(rows, C) bytes or more; the
+ * GEMM workspace serves, calls are stream-ordered): the per-row-slab column sums pass through it and are added in a fixed
+ * order, so batch statistics and dgamma / dbeta are the same bits from run to run.  The entry points above add them with
+ * float atomics in arrival order (so does this one when the buffer is absent or too small). */
+int64_t vitk_batchnorm_workspace_bytes(int64_t rows, int64_t C);
+int vitk_batchnorm_fwd_ws(const void* x, const float* gamma, const float* beta, float* running_mean, float* running_var,
+	void* y, float* save_mean, float* save_rstd, int64_t rows, int64_t C, float eps, float momentum, int training, int dtype,
+	void* workspace, int64_t workspace_bytes, void* stream);
+int vitk_batchnorm_bwd_ws(const void* dy, const void* x, const float* gamma, const float* save_mean, const float* save_rstd,
+	void* dx, float* dgamma, float* dbeta, int64_t rows, int64_t C, int training, int dtype, void* workspace,
+	int64_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }

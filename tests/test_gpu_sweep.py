@@ -438,6 +438,51 @@ def test_conv_attention_many_rows(gpu, dtype, dim, heads, hw, stride, B):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("rows,C", [(512, 32), (8 * 1024, 64), (50000, 24), (3000, 100), (70, 8)])
+def test_batchnorm_sums_are_bit_reproducible(gpu, dtype, rows, C):
+	"""BatchNorm through the scratch buffer (vitk_batchnorm_{fwd,bwd}_ws, what the conv embedding and MBConv run): the
+	per-row-slab column sums are added in a fixed order, so outputs, saved statistics, dx, dgamma and dbeta are the same BITS
+	in every call (with float atomics in arrival order -- the entry points without a buffer -- a statistic moves in its
+	last bit now and then, which flips bf16 roundings of the normalised activations and of everything behind them); and
+	both forms agree with the float64 formulas."""
+	from vit_amd import ops
+	import vit_amd._lib as L
+	g = torch.Generator().manual_seed(rows + C)
+	x = (torch.randn(rows, C, generator=g) * 2 + 0.5).to(gpu).to(dtype)
+	dy = torch.randn(rows, C, generator=g).to(gpu).to(dtype)
+	gamma = (torch.rand(C, generator=g) + 0.5).to(gpu)
+	beta = torch.randn(C, generator=g).to(gpu)
+	outs = []
+	for it in range(6):
+		junk = torch.full((1 << 18,), float("nan"), device=gpu)  # (whatever the scratch buffer and fresh allocations held before)
+		ops.gemm_workspace(gpu).view(torch.float32)[:1 << 18].copy_(junk)
+		del junk
+		rm, rv = torch.zeros(C, device=gpu), torch.ones(C, device=gpu)
+		y, mean, rstd = torch.empty_like(x), torch.empty(C, device=gpu), torch.empty(C, device=gpu)
+		ops.batchnorm_fwd(x, gamma, beta, rm, rv, y, mean, rstd, 1e-5, 0.1, True)
+		dx, dg, db = torch.empty_like(x), torch.empty(C, device=gpu), torch.empty(C, device=gpu)
+		ops.batchnorm_bwd(dy, x, gamma, mean, rstd, dx, dg, db, True)
+		outs.append([t.clone() for t in (y, mean, rstd, rm, rv, dx, dg, db)])
+	for o in outs[1:]:
+		assert all(torch.equal(a, b) for a, b in zip(o, outs[0]))
+	y, mean, rstd, rm, rv, dx, dg, db = outs[0]
+	xr = x.double().cpu().requires_grad_(True)
+	gr, br = gamma.double().cpu().requires_grad_(True), beta.double().cpu().requires_grad_(True)
+	yr = torch.nn.functional.batch_norm(xr, None, None, gr, br, True, 0.1, 1e-5)
+	yr.backward(dy.double().cpu())
+	tol = 1e-5 if dtype == torch.float32 else 2e-2
+	assert relerr(y, yr.detach()) < tol and relerr(dx, xr.grad) < tol
+	assert relerr(dg, gr.grad) < tol and relerr(db, br.grad) < tol
+	assert relerr(mean, x.double().cpu().mean(0)) < 1e-5
+	# the entry points without a buffer (float atomics): the same numbers to float32 rounding
+	lib = L.load()
+	y2, mean2, rstd2 = torch.empty_like(x), torch.empty(C, device=gpu), torch.empty(C, device=gpu)
+	L.check(lib.vitk_batchnorm_fwd(L.ptr(x), L.ptr(gamma), L.ptr(beta), L.ptr(torch.zeros(C, device=gpu)), L.ptr(torch.ones(C, device=gpu)), L.ptr(y2), L.ptr(mean2),
+		L.ptr(rstd2), rows, C, 1e-5, 0.1, 1, L.dtype_code(dtype), L.stream()))
+	assert relerr(mean2, mean.double()) < 1e-5 and relerr(rstd2, rstd.double()) < 1e-5 and relerr(y2, y.double()) < (1e-5 if dtype == torch.float32 else 1e-2)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("C,ks,stride,hw,B", [(64, 3, 1, 8, 5), (128, 3, 2, 7, 3), (20, 3, 1, 6, 4), (16, 5, 2, 9, 3)])
 def test_depthwise_conv_on_column_slices(gpu, dtype, C, ks, stride, hw, B):
 	"""vitk_dwconv_fwd_ld / vitk_dwconv_bwd_ld: the input and the input gradient as column slices of wider buffers (K | V of

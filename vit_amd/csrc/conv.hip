@@ -346,7 +346,7 @@ __global__ __launch_bounds__(256) void pad_cols_kernel(const TI* __restrict__ sr
 // pass A: out0[c] += sum_r f0, out1[c] += sum_r f1 with (f0, f1) = (x, -) | ((x-mean)^2, -) | (dy, dy * xhat)
 template <typename T, int MODE>
 __global__ __launch_bounds__(256) void bn_colreduce_kernel(const T* __restrict__ x, const T* __restrict__ dy, const float* __restrict__ mean,
-	const float* __restrict__ rstd, float* out0, float* out1, int64_t rows, int C) {
+	const float* __restrict__ rstd, float* out0, float* out1, int64_t rows, int C, float* partials) {
 	const int c = blockIdx.x * 64 + (threadIdx.x & 63);
 	const int sub = threadIdx.x >> 6;
 	__shared__ float red0[4][64], red1[4][64];
@@ -372,15 +372,47 @@ __global__ __launch_bounds__(256) void bn_colreduce_kernel(const T* __restrict__
 	__syncthreads();
 	if (sub == 0 && c < C) {
 		const int l = threadIdx.x;
-		atomicAdd(&out0[c], red0[0][l] + red0[1][l] + red0[2][l] + red0[3][l]);
-		if (MODE == 2) atomicAdd(&out1[c], red1[0][l] + red1[1][l] + red1[2][l] + red1[3][l]);
+		const float s0 = red0[0][l] + red0[1][l] + red0[2][l] + red0[3][l], s1 = red1[0][l] + red1[1][l] + red1[2][l] + red1[3][l];
+		if (partials != nullptr) {  // [row slab][sum][C]: added up in slab order by bn_partials_sum_kernel
+			partials[((int64_t)blockIdx.y * 2 + 0) * C + c] = s0;
+			if (MODE == 2) partials[((int64_t)blockIdx.y * 2 + 1) * C + c] = s1;
+		} else {
+			atomicAdd(&out0[c], s0);
+			if (MODE == 2) atomicAdd(&out1[c], s1);
+		}
+	}
+}
+
+// out0[c] (and out1[c]) = sum over the row slabs of partials[slab][0 (1)][c], in a FIXED order (64 lanes take the slabs
+// l, l + 64, ... in turn; the lane sums are then added 0 + 1 + ... + 63): the column sums of a BatchNorm are then the same
+// bits from run to run, which float atomics in arrival order are not (a batch statistic that moves in its last bit flips
+// bf16 roundings of the normalised activations, and everything behind them).  Workgroup = 4 channels x 64 lanes (up to
+// 2048 slabs: 32 loads per lane).
+__global__ __launch_bounds__(256) void bn_partials_sum_kernel(const float* __restrict__ partials, int slabs, int C, float* __restrict__ out0, float* __restrict__ out1) {
+	__shared__ float red[2][64][4];
+	const int cl = threadIdx.x & 3, lane = threadIdx.x >> 2;
+	const int c = blockIdx.x * 4 + cl;
+	float a0 = 0.f, a1 = 0.f;
+	if (c < C) {
+		for (int sl = lane; sl < slabs; sl += 64) {
+			a0 += partials[((int64_t)sl * 2 + 0) * C + c];
+			if (out1 != nullptr) a1 += partials[((int64_t)sl * 2 + 1) * C + c];
+		}
+	}
+	red[0][lane][cl] = a0;
+	red[1][lane][cl] = a1;
+	__syncthreads();
+	if (lane < 2 && c < C && (lane == 0 || out1 != nullptr)) {  // lane 0: the first sum, lane 1: the second
+		float s = 0.f;
+		for (int l = 0; l < 64; ++l) s += red[lane][l][cl];
+		(lane == 0 ? out0 : out1)[c] = s;
 	}
 }
 
 // The same in 16-byte channel groups (C % V == 0): workgroup = 16 channel groups x 16 row lanes.
 template <typename T, int V, int MODE>
 __global__ __launch_bounds__(256) void bn_colreduce_vec_kernel(const T* __restrict__ x, const T* __restrict__ dy, const float* __restrict__ mean,
-	const float* __restrict__ rstd, float* out0, float* out1, int64_t rows, int C) {
+	const float* __restrict__ rstd, float* out0, float* out1, int64_t rows, int C, float* partials) {
 	__shared__ float red0[16][16 * V + 1], red1[16][16 * V + 1];
 	const int cgl = threadIdx.x & 15, rl = threadIdx.x >> 4;
 	const int cg = blockIdx.x * 16 + cgl;
@@ -430,8 +462,13 @@ __global__ __launch_bounds__(256) void bn_colreduce_vec_kernel(const T* __restri
 				s0 += red0[l][threadIdx.x];
 				s1 += red1[l][threadIdx.x];
 			}
-			atomicAdd(&out0[c], s0);
-			if (MODE == 2) atomicAdd(&out1[c], s1);
+			if (partials != nullptr) {
+				partials[((int64_t)blockIdx.y * 2 + 0) * C + c] = s0;
+				if (MODE == 2) partials[((int64_t)blockIdx.y * 2 + 1) * C + c] = s1;
+			} else {
+				atomicAdd(&out0[c], s0);
+				if (MODE == 2) atomicAdd(&out1[c], s1);
+			}
 		}
 	}
 }
@@ -671,8 +708,29 @@ extern "C" int vitk_col2im(const void* cols, void* dx, int64_t B, int64_t C, int
 	});
 }
 
-extern "C" int vitk_batchnorm_fwd(const void* x, const float* gamma, const float* beta, float* running_mean, float* running_var, void* y, float* save_mean,
-	float* save_rstd, int64_t rows, int64_t C, float eps, float momentum, int training, int dtype, void* stream) {
+// With a workspace (16-byte aligned, at least 2 * slabs * C floats for the grid chosen here: vitk_batchnorm_workspace_bytes)
+// the per-slab column sums pass through it and are added in a fixed order: the batch statistics and the parameter gradients
+// are then bit-reproducible from run to run.  Without one they are added with float atomics in arrival order.
+extern "C" int64_t vitk_batchnorm_workspace_bytes(int64_t rows, int64_t C) {
+	if (rows <= 0 || C <= 0) return 0;
+	// (the most row slabs any of the paths may choose: element-wise, 16-byte groups of 4 floats or of 8 bf16)
+	const unsigned slabs = std::max(colgrid(rows, (int)C).y, std::max(colgrid_vec(rows, (int)vitk_cdiv(C, 4)).y, colgrid_vec(rows, (int)vitk_cdiv(C, 8)).y));
+	return (int64_t)slabs * 2 * C * (int64_t)sizeof(float);
+}
+
+namespace {
+// partial-sum buffer for a reduction launched on `slabs` row slabs, or nullptr when the caller's workspace is absent / too small
+inline float* bn_partials(void* ws, int64_t ws_bytes, unsigned slabs, int64_t C) {
+	if (ws == nullptr || !vitk_aligned(ws, 16) || ws_bytes < (int64_t)slabs * 2 * C * (int64_t)sizeof(float)) return nullptr;
+	return reinterpret_cast<float*>(ws);
+}
+inline void bn_sum(float* partials, unsigned slabs, int64_t C, float* out0, float* out1, hipStream_t st) {
+	if (partials != nullptr) hipLaunchKernelGGL(bn_partials_sum_kernel, dim3((unsigned)vitk_cdiv(C, 4)), dim3(256), 0, st, partials, (int)slabs, (int)C, out0, out1);
+}
+}  // namespace
+
+extern "C" int vitk_batchnorm_fwd_ws(const void* x, const float* gamma, const float* beta, float* running_mean, float* running_var, void* y, float* save_mean,
+	float* save_rstd, int64_t rows, int64_t C, float eps, float momentum, int training, int dtype, void* workspace, int64_t workspace_bytes, void* stream) {
 	VITK_REQUIRE(x && gamma && beta && running_mean && running_var && y, VITK_ERR_NULL);
 	VITK_REQUIRE(rows > 0 && C > 0 && C < (1 << 30), VITK_ERR_SHAPE);
 	hipStream_t st = (hipStream_t)stream;
@@ -701,17 +759,23 @@ extern "C" int vitk_batchnorm_fwd(const void* x, const float* gamma, const float
 		constexpr int V = VecOf<T>::N;
 		if (C % V == 0 && vitk_aligned(x, 16) && vitk_aligned(y, 16)) {
 			const dim3 vg = colgrid_vec(rows, (int)C / V);
-			hipLaunchKernelGGL((bn_colreduce_vec_kernel<T, V, 0>), vg, dim3(256), 0, st, (const T*)x, (const T*)nullptr, nullptr, nullptr, save_mean, nullptr, rows, (int)C);
+			float* part = bn_partials(workspace, workspace_bytes, vg.y, C);
+			hipLaunchKernelGGL((bn_colreduce_vec_kernel<T, V, 0>), vg, dim3(256), 0, st, (const T*)x, (const T*)nullptr, nullptr, nullptr, save_mean, nullptr, rows, (int)C, part);
+			bn_sum(part, vg.y, C, save_mean, nullptr, st);
 			hipLaunchKernelGGL((bn_finalize_kernel<0>), dim3(fg), dim3(256), 0, st, save_mean, save_rstd, running_mean, running_var, rows, (int)C, eps, momentum);
-			hipLaunchKernelGGL((bn_colreduce_vec_kernel<T, V, 1>), vg, dim3(256), 0, st, (const T*)x, (const T*)nullptr, save_mean, nullptr, save_rstd, nullptr, rows, (int)C);
+			hipLaunchKernelGGL((bn_colreduce_vec_kernel<T, V, 1>), vg, dim3(256), 0, st, (const T*)x, (const T*)nullptr, save_mean, nullptr, save_rstd, nullptr, rows, (int)C, part);
+			bn_sum(part, vg.y, C, save_rstd, nullptr, st);
 			hipLaunchKernelGGL((bn_finalize_kernel<1>), dim3(fg), dim3(256), 0, st, save_mean, save_rstd, running_mean, running_var, rows, (int)C, eps, momentum);
 			hipLaunchKernelGGL((bn_apply_vec_kernel<T, V>), vg, dim3(256), 0, st, (const T*)x, gamma, beta, save_mean, save_rstd, (T*)y, rows, (int)C, eps, 0);
 			VITK_CHECK_LAUNCH();
 			return VITK_OK;
 		}
-		hipLaunchKernelGGL((bn_colreduce_kernel<T, 0>), cg, dim3(256), 0, st, (const T*)x, (const T*)nullptr, nullptr, nullptr, save_mean, nullptr, rows, (int)C);
+		float* part = bn_partials(workspace, workspace_bytes, cg.y, C);
+		hipLaunchKernelGGL((bn_colreduce_kernel<T, 0>), cg, dim3(256), 0, st, (const T*)x, (const T*)nullptr, nullptr, nullptr, save_mean, nullptr, rows, (int)C, part);
+		bn_sum(part, cg.y, C, save_mean, nullptr, st);
 		hipLaunchKernelGGL((bn_finalize_kernel<0>), dim3(fg), dim3(256), 0, st, save_mean, save_rstd, running_mean, running_var, rows, (int)C, eps, momentum);
-		hipLaunchKernelGGL((bn_colreduce_kernel<T, 1>), cg, dim3(256), 0, st, (const T*)x, (const T*)nullptr, save_mean, nullptr, save_rstd, nullptr, rows, (int)C);
+		hipLaunchKernelGGL((bn_colreduce_kernel<T, 1>), cg, dim3(256), 0, st, (const T*)x, (const T*)nullptr, save_mean, nullptr, save_rstd, nullptr, rows, (int)C, part);
+		bn_sum(part, cg.y, C, save_rstd, nullptr, st);
 		hipLaunchKernelGGL((bn_finalize_kernel<1>), dim3(fg), dim3(256), 0, st, save_mean, save_rstd, running_mean, running_var, rows, (int)C, eps, momentum);
 		hipLaunchKernelGGL((bn_apply_kernel<T>), dim3(vitk_stream_grid(n, 256)), dim3(256), 0, st, (const T*)x, gamma, beta, save_mean, save_rstd, (T*)y, n, (int)C, eps, 0);
 		VITK_CHECK_LAUNCH();
@@ -719,8 +783,13 @@ extern "C" int vitk_batchnorm_fwd(const void* x, const float* gamma, const float
 	});
 }
 
-extern "C" int vitk_batchnorm_bwd(const void* dy, const void* x, const float* gamma, const float* save_mean, const float* save_rstd, void* dx, float* dgamma,
-	float* dbeta, int64_t rows, int64_t C, int training, int dtype, void* stream) {
+extern "C" int vitk_batchnorm_fwd(const void* x, const float* gamma, const float* beta, float* running_mean, float* running_var, void* y, float* save_mean,
+	float* save_rstd, int64_t rows, int64_t C, float eps, float momentum, int training, int dtype, void* stream) {
+	return vitk_batchnorm_fwd_ws(x, gamma, beta, running_mean, running_var, y, save_mean, save_rstd, rows, C, eps, momentum, training, dtype, nullptr, 0, stream);
+}
+
+extern "C" int vitk_batchnorm_bwd_ws(const void* dy, const void* x, const float* gamma, const float* save_mean, const float* save_rstd, void* dx, float* dgamma,
+	float* dbeta, int64_t rows, int64_t C, int training, int dtype, void* workspace, int64_t workspace_bytes, void* stream) {
 	VITK_REQUIRE(dy && x && gamma && save_mean && save_rstd && dx && dgamma && dbeta, VITK_ERR_NULL);
 	VITK_REQUIRE(rows > 0 && C > 0 && C < (1 << 30), VITK_ERR_SHAPE);
 	hipStream_t st = (hipStream_t)stream;
@@ -732,19 +801,28 @@ extern "C" int vitk_batchnorm_bwd(const void* dy, const void* x, const float* ga
 	DISPATCH_T(dtype, {
 		constexpr int V = VecOf<T>::N;
 		if (C % V == 0 && vitk_aligned(x, 16) && vitk_aligned(dy, 16) && vitk_aligned(dx, 16)) {
-			hipLaunchKernelGGL((bn_colreduce_vec_kernel<T, V, 2>), colgrid_vec(rows, (int)C / V), dim3(256), 0, st, (const T*)x, (const T*)dy, save_mean, save_rstd, dbeta, dgamma,
-				rows, (int)C);
-			hipLaunchKernelGGL((bn_bwd_apply_vec_kernel<T, V>), colgrid_vec(rows, (int)C / V), dim3(256), 0, st, (const T*)dy, (const T*)x, gamma, save_mean, save_rstd, dgamma,
+			const dim3 vg = colgrid_vec(rows, (int)C / V);
+			float* part = bn_partials(workspace, workspace_bytes, vg.y, C);
+			hipLaunchKernelGGL((bn_colreduce_vec_kernel<T, V, 2>), vg, dim3(256), 0, st, (const T*)x, (const T*)dy, save_mean, save_rstd, dbeta, dgamma, rows, (int)C, part);
+			bn_sum(part, vg.y, C, dbeta, dgamma, st);
+			hipLaunchKernelGGL((bn_bwd_apply_vec_kernel<T, V>), vg, dim3(256), 0, st, (const T*)dy, (const T*)x, gamma, save_mean, save_rstd, dgamma,
 				dbeta, (T*)dx, rows, (int)C, 1.0f / (float)rows, training);
 			VITK_CHECK_LAUNCH();
 			return VITK_OK;
 		}
-		hipLaunchKernelGGL((bn_colreduce_kernel<T, 2>), cg, dim3(256), 0, st, (const T*)x, (const T*)dy, save_mean, save_rstd, dbeta, dgamma, rows, (int)C);
+		float* part = bn_partials(workspace, workspace_bytes, cg.y, C);
+		hipLaunchKernelGGL((bn_colreduce_kernel<T, 2>), cg, dim3(256), 0, st, (const T*)x, (const T*)dy, save_mean, save_rstd, dbeta, dgamma, rows, (int)C, part);
+		bn_sum(part, cg.y, C, dbeta, dgamma, st);
 		hipLaunchKernelGGL((bn_bwd_apply_kernel<T>), dim3(vitk_stream_grid(n, 256)), dim3(256), 0, st, (const T*)dy, (const T*)x, gamma, save_mean, save_rstd, dgamma, dbeta,
 			(T*)dx, n, (int)C, 1.0f / (float)rows, training);
 		VITK_CHECK_LAUNCH();
 		return VITK_OK;
 	});
+}
+
+extern "C" int vitk_batchnorm_bwd(const void* dy, const void* x, const float* gamma, const float* save_mean, const float* save_rstd, void* dx, float* dgamma,
+	float* dbeta, int64_t rows, int64_t C, int training, int dtype, void* stream) {
+	return vitk_batchnorm_bwd_ws(dy, x, gamma, save_mean, save_rstd, dx, dgamma, dbeta, rows, C, training, dtype, nullptr, 0, stream);
 }
 
 extern "C" int vitk_pad_cols(const void* src, void* dst, int64_t rows, int64_t cols, int64_t ld_src, int64_t ld_dst, int src_dtype, int dst_dtype, void* stream) {

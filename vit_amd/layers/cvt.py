@@ -6,8 +6,10 @@ import torch.nn as nn
 from .. import ops
 from .attention import ConvAttention
 from .dropout import Dropout
-from .norm import apply_norm
+from .norm import DyT, apply_norm, norm_spec
 from .transformers import FeedForward
+
+FUSED_BLOCK = True  # one autograd node per block (ops.CvTBlockFn) where the block allows it; False: always module by module
 
 
 class CvTBlock(nn.Module):
@@ -25,7 +27,24 @@ class CvTBlock(nn.Module):
 		self.ff_layer_scale = nn.Parameter(torch.full((self.d_model,), 1e-4)) if use_ls else None
 		self.ff_dropout = Dropout(config.dropout)
 
+	def _fusable(self):
+		if not FUSED_BLOCK or isinstance(self.attn_norm, DyT) or isinstance(self.ff_norm, DyT):
+			return False
+		drops = (self.attn.dropout, self.attn_dropout, self.ff.dropout1, self.ff.dropout2, self.ff_dropout)
+		return not any(m.active() for m in drops)
+
 	def forward(self, x, h, w):
+		if self._fusable():
+			kind, n1w, n1b, eps, off = norm_spec(self.attn_norm)
+			kind2, n2w, n2b, eps2, off2 = norm_spec(self.ff_norm)
+			assert (kind, eps, off) == (kind2, eps2, off2)
+			at = self.attn
+			cfg = (kind, eps, off, h, w, at.n_head, at.kernel_size, at.qkv_stride, at.padding, self.ff.act_code, self.ff.gated)
+			y = ops.CvTBlockFn.apply(x, n1w, n1b, at.q_proj.weight, at.q_proj.bias, at.k_proj.weight, at.k_proj.bias, at.v_proj.weight, at.v_proj.bias,
+				at.conv_proj_k.weight, at.conv_proj_v.weight, at.out_proj.weight, at.out_proj.bias, self.attn_layer_scale,
+				n2w, n2b, self.ff.fc_in.weight, self.ff.fc_in.bias, self.ff.fc_out.weight, self.ff.fc_out.bias, self.ff_layer_scale, cfg)
+			return y, h, w
+		# module-by-module composition (an active dropout, or DyT in place of a norm)
 		branch = self.attn_dropout(self.attn(apply_norm(self.attn_norm, x), h, w))
 		x = ops.ScaleResidualFn.apply(branch, x, self.attn_layer_scale)
 		branch = self.ff_dropout(self.ff(apply_norm(self.ff_norm, x)))

@@ -1421,6 +1421,24 @@ def dropout(x, p):
 # CvT: conv token embedding, conv-projection attention, mean pool
 # --------------------------------------------------------------------------------------------------
 
+def batchnorm_fwd(x, gamma, beta, running_mean, running_var, y, save_mean, save_rstd, eps, momentum, training):
+	"""vitk_batchnorm_fwd_ws over x [rows, C]: the column sums pass through the GEMM scratch buffer and are added in a fixed
+	order (bit-reproducible batch statistics)."""
+	rows, C = x.shape
+	ws = gemm_workspace(x.device)
+	assert ws.numel() >= L.load().vitk_batchnorm_workspace_bytes(rows, C), "scratch buffer smaller than the BatchNorm partial sums"
+	L.check(L.load().vitk_batchnorm_fwd_ws(L.ptr(x), L.ptr(gamma), L.ptr(beta), L.ptr(running_mean), L.ptr(running_var), L.ptr(y), L.ptr(save_mean), L.ptr(save_rstd),
+		rows, C, eps, momentum, int(training), L.dtype_code(x.dtype), ws.data_ptr(), ws.numel(), L.stream()))
+
+
+def batchnorm_bwd(dy, x, gamma, save_mean, save_rstd, dx, dgamma, dbeta, training):
+	rows, C = x.shape
+	ws = gemm_workspace(x.device)
+	assert ws.numel() >= L.load().vitk_batchnorm_workspace_bytes(rows, C), "scratch buffer smaller than the BatchNorm partial sums"
+	L.check(L.load().vitk_batchnorm_bwd_ws(L.ptr(dy), L.ptr(x), L.ptr(gamma), L.ptr(save_mean), L.ptr(save_rstd), L.ptr(dx), L.ptr(dgamma), L.ptr(dbeta),
+		rows, C, int(training), L.dtype_code(x.dtype), ws.data_ptr(), ws.numel(), L.stream()))
+
+
 def _conv_out(n, ks, stride, pad):
 	return (n + 2 * pad - ks) // stride + 1
 
@@ -1460,8 +1478,7 @@ class ConvEmbedFn(torch.autograd.Function):
 		y = torch.empty_like(y0)
 		save_mean = torch.empty(Cout, dtype=torch.float32, device=x.device)
 		save_rstd = torch.empty(Cout, dtype=torch.float32, device=x.device)
-		L.check(lib.vitk_batchnorm_fwd(L.ptr(y0), L.ptr(f32(bn_w)), L.ptr(f32(bn_b)), L.ptr(running_mean), L.ptr(running_var), L.ptr(y),
-			L.ptr(save_mean), L.ptr(save_rstd), rows, Cout, eps, momentum, int(training), dtc, L.stream()))
+		batchnorm_fwd(y0, f32(bn_w), f32(bn_b), running_mean, running_var, y, save_mean, save_rstd, eps, momentum, training)
 		ctx.save_for_backward(cols, y0, save_mean, save_rstd, conv_w, bn_w)
 		ctx.meta = (x.shape, x.dtype, bn_b, cfg, dt, (Bn, C, H, W, Ho, Wo, tokens_in))
 		return y.reshape(Bn, Ho * Wo, Cout)
@@ -1478,8 +1495,7 @@ class ConvEmbedFn(torch.autograd.Function):
 		dy0 = torch.empty_like(y0)
 		dgamma = torch.empty(Cout, dtype=torch.float32, device=dy.device)
 		dbeta = torch.empty(Cout, dtype=torch.float32, device=dy.device)
-		L.check(lib.vitk_batchnorm_bwd(L.ptr(dy2), L.ptr(y0), L.ptr(f32(bn_w)), L.ptr(save_mean), L.ptr(save_rstd), L.ptr(dy0), L.ptr(dgamma), L.ptr(dbeta),
-			rows, Cout, int(training), dtc, L.stream()))
+		batchnorm_bwd(dy2, y0, f32(bn_w), save_mean, save_rstd, dy0, dgamma, dbeta, training)
 		K = conv_w[0].numel()
 		Kp = cols.shape[1]  # K, or K padded with zero columns
 		dw = linear_wgrad(dy0, cols)
@@ -1550,6 +1566,52 @@ def _stacked(ts):
 	return j if j is not None else torch.cat(ts, dim=0)
 
 
+def _conv_attn_forward(x2, wqkv, bqkv, ckv, wo, bo, geom, residual=None, drop=(0.0, 0)):
+	"""Joint q | k | v projection -> depthwise convolution of K | V -> attention -> output projection (+ residual in its
+	epilogue).  geom = (Bn, H, W, n_head, ks, stride, pad).  Returns (y, qkv, kv1, o, lse, Skv)."""
+	Bn, H, W, n_head, ks, stride, pad = geom
+	C = x2.shape[1]
+	qkv = linear_fwd(x2, wqkv, bqkv)  # [tokens, 3C]: q | k | v
+	kv1, Skv = dwconv_fwd(qkv[:, C:], ckv, Bn, H, W, 2 * C, ks, stride, pad)  # [Bn * Skv, 2C]: k | v
+	o, lse = attention_fwd(qkv[:, :C], kv1[:, :C], kv1[:, C:], Bn, n_head, H * W, Skv, C // n_head, drop=drop)
+	y = linear_fwd(o, wo, bo, residual=residual)
+	return y, qkv, kv1, o, lse, Skv
+
+
+def _conv_attn_backward(dy2, x2, qkv, kv1, o, lse, wqkv, ckv, wo, geom, Skv, sk, need_dx=True, drop=(0.0, 0)):
+	"""Backward of _conv_attn_forward.  sk: a _Sinks over the names wq bq wk bk wv bv wo bo.  Returns (dx, [dwq, dwk, dwv],
+	[dbq, dbk, dbv], dckv, dwo, dbo) with the parameter gradients as autograd wants them (None where a sink took them)."""
+	Bn, H, W, n_head, ks, stride, pad = geom
+	C = x2.shape[1]
+	dwo, dbo = linear_wgrad(dy2, o, bias_grad=True, dw_out=sk.buf("wo"), db_out=sk.buf("bo"))
+	do = linear_dgrad(dy2, wo)
+	dqkv = torch.empty_like(qkv)
+	dkv1 = torch.empty_like(kv1)
+	attention_bwd(do, qkv[:, :C], kv1[:, :C], kv1[:, C:], o, lse, dqkv[:, :C], dkv1[:, :C], dkv1[:, C:], Bn, n_head, H * W, Skv, C // n_head, drop=drop)
+	_, dckv = dwconv_bwd(dkv1, qkv[:, C:], ckv, Bn, H, W, 2 * C, ks, stride, pad, dx=dqkv[:, C:])
+	# the stacked weight / bias gradients go straight into the three neighbouring sinks where there are such; slices of
+	# a gradient whose sinks are apart (or absent) are added by hand (or handed to autograd)
+	w_sink = _joint([sk.buf("wq"), sk.buf("wk"), sk.buf("wv")])
+	b_sink = _joint([sk.buf("bq"), sk.buf("bk"), sk.buf("bv")])
+	dw3, db3 = linear_wgrad(dqkv, x2, bias_grad=True, dw_out=w_sink, db_out=b_sink)
+
+	def hand_out(names, joint_sink, g3):
+		out = []
+		for i, name in enumerate(names):
+			if joint_sink is None and sk.buf(name) is not None:
+				sk.buf(name).add_(g3[i * C:(i + 1) * C])
+			out.append(sk.ret(name, g3[i * C:(i + 1) * C]))
+		return out
+	gw = hand_out(("wq", "wk", "wv"), w_sink, dw3)
+	gb = hand_out(("bq", "bk", "bv"), b_sink, db3)
+	dx = None
+	if need_dx:
+		# dx = [dq | dk | dv] @ [Wq; Wk; Wv]: the weight as an MN-major operand (row n of the stacked weight is k-index n)
+		dx = torch.empty((x2.shape[0], C), dtype=x2.dtype, device=x2.device)
+		gemm(dqkv, wqkv, dx, x2.shape[0], C, 3 * C, 3 * C, C, C, b_layout=L.MN_MAJOR)
+	return dx, gw, gb, dckv, sk.ret("wo", dwo), sk.ret("bo", dbo)
+
+
 class ConvAttentionFn(torch.autograd.Function):
 	"""CvT attention (layers/attention.py:67-93 of the reference): q/k/v Linear (with bias), depthwise conv on K and V
 	applied directly to token-major activations, attention with Skv <= Sq, output projection.
@@ -1569,58 +1631,92 @@ class ConvAttentionFn(torch.autograd.Function):
 		dt = compute_dtype(x)
 		Bn, S, C = x.shape
 		assert S == H * W
-		dh = C // n_head
 		x2 = _flat(cast(x, dt))
 		wqkv = _stacked([weight_as(wq, dt), weight_as(wk, dt), weight_as(wv, dt)])
 		bqkv = _stacked([f32(bq), f32(bk), f32(bv)])
 		ckv = _stacked([weight_as(ck, dt), weight_as(cv, dt)])
-		qkv = linear_fwd(x2, wqkv, bqkv)  # [tokens, 3C]: q | k | v
-		kv1, Skv = dwconv_fwd(qkv[:, C:], ckv, Bn, H, W, 2 * C, ks, stride, pad)  # [Bn * Skv, 2C]: k | v
-		o, lse = attention_fwd(qkv[:, :C], kv1[:, :C], kv1[:, C:], Bn, n_head, S, Skv, dh, drop=drop)
-		y = linear_fwd(o, weight_as(wo, dt), f32(bo))
+		geom = (Bn, H, W, n_head, ks, stride, pad)
+		y, qkv, kv1, o, lse, Skv = _conv_attn_forward(x2, wqkv, bqkv, ckv, weight_as(wo, dt), f32(bo), geom, drop=drop)
 		ctx.save_for_backward(x2, qkv, kv1, o, lse, wq, wk, wv, ck, cv, wo, wqkv, ckv)
-		ctx.meta = (x.shape, x.dtype, (bq, bk, bv, bo), cfg, dt, Skv)
+		ctx.meta = (x.shape, x.dtype, (bq, bk, bv, bo), geom, dt, Skv, drop)
 		return y.reshape(Bn, S, C)
 
 	@staticmethod
 	def backward(ctx, dy):
 		x2, qkv, kv1, o, lse, wq, wk, wv, ck, cv, wo, wqkv, ckv = ctx.saved_tensors
-		(Bn, S, C), xdtype, (bq, bk, bv, bo), cfg, dt, Skv = ctx.meta
-		H, W, n_head, ks, stride, pad = cfg[:6]
-		drop = cfg[6] if len(cfg) > 6 else (0.0, 0)
-		dh = C // n_head
+		(Bn, S, C), xdtype, (bq, bk, bv, bo), geom, dt, Skv, drop = ctx.meta
 		dy2 = _flat(cast(dy, dt))
 		sk = _Sinks(wq=wq, bq=bq, wk=wk, bk=bk, wv=wv, bv=bv, wo=wo, bo=bo)
-		dwo, dbo = linear_wgrad(dy2, o, bias_grad=True, dw_out=sk.buf("wo"), db_out=sk.buf("bo"))
-		do = linear_dgrad(dy2, weight_as(wo, dt))
-		dqkv = torch.empty_like(qkv)
-		dkv1 = torch.empty_like(kv1)
-		attention_bwd(do, qkv[:, :C], kv1[:, :C], kv1[:, C:], o, lse, dqkv[:, :C], dkv1[:, :C], dkv1[:, C:], Bn, n_head, S, Skv, dh, drop=drop)
-		_, dckv = dwconv_bwd(dkv1, qkv[:, C:], ckv, Bn, H, W, 2 * C, ks, stride, pad, dx=dqkv[:, C:])
-		# the stacked weight / bias gradients go straight into the three neighbouring sinks where there are such; slices of
-		# a gradient whose sinks are apart (or absent) are added by hand (or handed to autograd)
-		w_sink = _joint([sk.buf("wq"), sk.buf("wk"), sk.buf("wv")])
-		b_sink = _joint([sk.buf("bq"), sk.buf("bk"), sk.buf("bv")])
-		dw3, db3 = linear_wgrad(dqkv, x2, bias_grad=True, dw_out=w_sink, db_out=b_sink)
-
-		def hand_out(names, joint_sink, g3):
-			out = []
-			for i, name in enumerate(names):
-				if joint_sink is None and sk.buf(name) is not None:
-					sk.buf(name).add_(g3[i * C:(i + 1) * C])
-				out.append(sk.ret(name, g3[i * C:(i + 1) * C]))
-			return out
-		gw = hand_out(("wq", "wk", "wv"), w_sink, dw3)
-		gb = hand_out(("bq", "bk", "bv"), b_sink, db3)
-		dx = None
-		if ctx.needs_input_grad[0]:
-			# dx = [dq | dk | dv] @ [Wq; Wk; Wv]: the weight as an MN-major operand (row n of the stacked weight is k-index n)
-			dx = torch.empty((Bn * S, C), dtype=dt, device=dy.device)
-			gemm(dqkv, wqkv, dx, Bn * S, C, 3 * C, 3 * C, C, C, b_layout=L.MN_MAJOR)
+		dx, gw, gb, dckv, gwo, gbo = _conv_attn_backward(dy2, x2, qkv, kv1, o, lse, wqkv, ckv, weight_as(wo, dt), geom, Skv, sk, ctx.needs_input_grad[0], drop)
+		if dx is not None:
 			dx = dx.reshape(Bn, S, C)
 			if dx.dtype != xdtype:
 				dx = cast(dx, xdtype)
-		return (dx, gw[0], gb[0], gw[1], gb[1], gw[2], gb[2], grad_as(dckv[:C], ck), grad_as(dckv[C:], cv), sk.ret("wo", dwo), sk.ret("bo", dbo), None)
+		return (dx, gw[0], gb[0], gw[1], gb[1], gw[2], gb[2], grad_as(dckv[:C], ck), grad_as(dckv[C:], cv), gwo, gbo, None)
+
+
+class CvTBlockFn(torch.autograd.Function):
+	"""One CvT block (layers/cvt.py:8-50 of the reference) as a single autograd node: norm -> joint q | k | v GEMM ->
+	depthwise convolution of K | V -> attention -> output projection (+ bias, + residual in the epilogue) -> norm ->
+	fc_in GEMM (+ bias, + activation) -> fc_out GEMM (+ bias, + residual in the epilogue); the backward adds the residual
+	gradients inside the norm backward kernels.  With LayerScale the residual add is a separate kernel (the branch output
+	is needed for the LayerScale gradient).  No dropout: a block with an active dropout runs module by module."""
+
+	@staticmethod
+	def forward(ctx, x, n1w, n1b, wq, bq, wk, bk, wv, bv, ck, cv, wo, bo, ls1, n2w, n2b, w1, b1, w2, b2, ls2, cfg):
+		L.require_gpu(x, wq)
+		kind, eps, unit_offset, H, W, n_head, ks, stride, pad, act, gated = cfg
+		dt = compute_dtype(x)
+		Bn, S, C = x.shape
+		assert S == H * W
+		x0 = _flat(cast(x, dt))
+		wqkv = _stacked([weight_as(wq, dt), weight_as(wk, dt), weight_as(wv, dt)])
+		bqkv = _stacked([f32(bq), f32(bk), f32(bv)])
+		ckv = _stacked([weight_as(ck, dt), weight_as(cv, dt)])
+		geom = (Bn, H, W, n_head, ks, stride, pad)
+		n1, _, mean1, rstd1 = norm_fwd(x0, f32(n1w), f32(n1b), kind, eps, unit_offset)
+		if ls1 is None:
+			x1, qkv, kv1, o, lse, Skv = _conv_attn_forward(n1, wqkv, bqkv, ckv, weight_as(wo, dt), f32(bo), geom, residual=x0)
+			br1 = None
+		else:
+			br1, qkv, kv1, o, lse, Skv = _conv_attn_forward(n1, wqkv, bqkv, ckv, weight_as(wo, dt), f32(bo), geom)
+			x1 = scale_residual(br1, x0, f32(ls1))
+		n2, _, mean2, rstd2 = norm_fwd(x1, f32(n2w), f32(n2b), kind, eps, unit_offset)
+		w1_c, w2_c = weight_as(w1, dt), weight_as(w2, dt)
+		if ls2 is None:
+			x2, u, a = _ffn_forward(n2, w1_c, f32(b1), w2_c, f32(b2), act, gated, residual=x1)
+			br2 = None
+		else:
+			br2, u, a = _ffn_forward(n2, w1_c, f32(b1), w2_c, f32(b2), act, gated)
+			x2 = scale_residual(br2, x1, f32(ls2))
+		ctx.save_for_backward(x0, n1, mean1, rstd1, qkv, kv1, o, lse, br1, x1, n2, mean2, rstd2, u, a, br2, wqkv, ckv,
+			n1w, wq, wk, wv, ck, cv, wo, ls1, n2w, w1, w2, ls2)
+		ctx.meta = (x.shape, x.dtype, (n1b, bq, bk, bv, bo, n2b, b1, b2), cfg, dt, geom, Skv)
+		return x2.reshape(Bn, S, C)
+
+	@staticmethod
+	def backward(ctx, dy):
+		(x0, n1, mean1, rstd1, qkv, kv1, o, lse, br1, x1, n2, mean2, rstd2, u, a, br2, wqkv, ckv,
+			n1w, wq, wk, wv, ck, cv, wo, ls1, n2w, w1, w2, ls2) = ctx.saved_tensors
+		(Bn, S, C), xdtype, (n1b, bq, bk, bv, bo, n2b, b1, b2), cfg, dt, geom, Skv = ctx.meta
+		kind, eps, unit_offset, H, W, n_head, ks, stride, pad, act, gated = cfg
+		sk = _Sinks(n1w=n1w, n1b=n1b, wq=wq, bq=bq, wk=wk, bk=bk, wv=wv, bv=bv, wo=wo, bo=bo, n2w=n2w, n2b=n2b, w1=w1, b1=b1, w2=w2, b2=b2)
+		dx2 = _flat(cast(dy, dt))
+		# feed-forward branch
+		dbr2, dls2 = layerscale_bwd(dx2, br2, f32(ls2)) if ls2 is not None else (dx2, None)
+		dn2, dw1, db1, dw2, db2 = _ffn_backward(dbr2, n2, u, a, weight_as(w1, dt), weight_as(w2, dt), act, gated,
+			outs=(sk.buf("w1"), sk.buf("b1"), sk.buf("w2"), sk.buf("b2")))
+		dx1, dn2w, dn2b = norm_bwd(dn2, x1, f32(n2w), mean2, rstd2, kind, unit_offset, dres=dx2, dw_out=sk.buf("n2w"), db_out=sk.buf("n2b"))
+		# attention branch
+		dbr1, dls1 = layerscale_bwd(dx1, br1, f32(ls1)) if ls1 is not None else (dx1, None)
+		dn1, gw, gb, dckv, gwo, gbo = _conv_attn_backward(dbr1, n1, qkv, kv1, o, lse, wqkv, ckv, weight_as(wo, dt), geom, Skv, sk)
+		dx0, dn1w, dn1b = norm_bwd(dn1, x0, f32(n1w), mean1, rstd1, kind, unit_offset, dres=dx1, dw_out=sk.buf("n1w"), db_out=sk.buf("n1b"))
+		dx0 = dx0.reshape(Bn, S, C)
+		if dx0.dtype != xdtype:
+			dx0 = cast(dx0, xdtype)
+		return (dx0, sk.ret("n1w", dn1w), sk.ret("n1b", dn1b), gw[0], gb[0], gw[1], gb[1], gw[2], gb[2], grad_as(dckv[:C], ck), grad_as(dckv[C:], cv),
+			gwo, gbo, grad_as(dls1, ls1), sk.ret("n2w", dn2w), sk.ret("n2b", dn2b), sk.ret("w1", dw1), sk.ret("b1", db1), sk.ret("w2", dw2), sk.ret("b2", db2),
+			grad_as(dls2, ls2), None)
 
 
 class MBConvFn(torch.autograd.Function):
@@ -1655,8 +1751,7 @@ class MBConvFn(torch.autograd.Function):
 			y = torch.empty_like(h)
 			mean = torch.empty(h.shape[1], dtype=torch.float32, device=h.device)
 			rstd = torch.empty(h.shape[1], dtype=torch.float32, device=h.device)
-			L.check(lib.vitk_batchnorm_fwd(L.ptr(h), L.ptr(f32(g)), L.ptr(f32(b)), L.ptr(rm), L.ptr(rv), L.ptr(y), L.ptr(mean), L.ptr(rstd),
-				h.shape[0], h.shape[1], eps, momentum, int(training), dtc, L.stream()))
+			batchnorm_fwd(h, f32(g), f32(b), rm, rv, y, mean, rstd, eps, momentum, training)
 			return y, mean, rstd
 
 		def act_fwd(u):
@@ -1702,8 +1797,7 @@ class MBConvFn(torch.autograd.Function):
 			dh = torch.empty_like(h)
 			dg = torch.empty(h.shape[1], dtype=torch.float32, device=h.device)
 			db = torch.empty(h.shape[1], dtype=torch.float32, device=h.device)
-			L.check(lib.vitk_batchnorm_bwd(L.ptr(dn), L.ptr(h), L.ptr(f32(g)), L.ptr(mean), L.ptr(rstd), L.ptr(dh), L.ptr(dg), L.ptr(db),
-				h.shape[0], h.shape[1], int(training), dtc, L.stream()))
+			batchnorm_bwd(dn, h, f32(g), mean, rstd, dh, dg, db, training)
 			return dh, dg, db
 
 		def act_bwd(da, pre):
