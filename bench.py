@@ -440,7 +440,11 @@ def main():
 			del model, trainer, x, y, loss, loss_of
 			torch.cuda.empty_cache()
 			secondary, sweep = [], []
-			runs = [("vit_tiny", dict()), ("vit_tiny", dict(graph=True)), ("deit_tiny", dict()), ("cvt", dict()), ("cvt", dict(graph=True)), ("coatnet", dict(steps=6)),
+			# (the small configurations take 5-7 ms a step and are host-bound when eager: 30 steps behind 5 warm-up steps, as the
+			# allocator and the launch path need more than three steps to settle)
+			quick = dict(steps=30, warmup=5)
+			runs = [("vit_tiny", dict(quick)), ("vit_tiny", dict(quick, graph=True)), ("deit_tiny", dict(quick)), ("cvt", dict(quick)), ("cvt", dict(quick, graph=True)),
+				("coatnet", dict(steps=6)),
 				("vit_b16", dict(dropout=0.3, steps=6))]
 			for name, kw in runs:
 				try:
