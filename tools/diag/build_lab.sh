@@ -1,5 +1,7 @@
 #!/bin/bash
 # builds diag_bin/gemm_lab and leaves the kernel's ISA in /tmp/lab
+# (the lab compiles its own copy of the kernel files AND links libvitk.so: the executable's definitions win, so the library's
+# dispatcher -- the lab's "old" column -- runs the lab's copy of those kernels too; to compare two versions build two labs)
 set -e
 cd "$(dirname "$0")/../.."
 mkdir -p diag_bin /tmp/lab
