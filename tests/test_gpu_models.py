@@ -359,6 +359,57 @@ def make_cvt(c, gpu):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("layer_scale,norm,act,stride", [(False, "rms", "silu", 1), (True, "rms", "silu", 2), (True, "ln", "gelu", 1), (False, "ln", "swiglu", 2)])
+def test_cvt_block_as_one_node_matches_module_by_module(gpu, dtype, layer_scale, norm, act, stride):
+	"""CvTBlock as ONE autograd node (ops.CvTBlockFn: residual adds in the GEMM epilogues, residual gradients inside the norm
+	backward kernels, LayerScale through the separate add) against the module-by-module composition of the same block (each
+	piece of which has its own golden / oracle test): output, input gradient and every parameter gradient, with and without
+	LayerScale, LayerNorm and RMSNorm, plain and gated feed-forward, K / V at stride 1 and 2."""
+	import vit_amd.layers.cvt as cvt_layers
+	from vit_amd.layers import RMSNorm
+	from vit_amd.layers.cvt import CvTBlock
+
+	class Cfg:
+		d_model, d_ff, n_head, dropout = 64, 128, 2, 0.0
+	Cfg.norm = RMSNorm if norm == "rms" else nn.LayerNorm
+	Cfg.activation, Cfg.use_layer_scale = act, layer_scale
+	torch.manual_seed(3)
+	blk = CvTBlock(Cfg(), 3, stride, 1).to(gpu)
+	with torch.no_grad():
+		for n, p in blk.named_parameters():
+			if n.endswith("layer_scale"):
+				p.uniform_(0.3, 0.9)
+			elif "norm" in n:
+				p.normal_(0.0 if norm == "rms" else 1.0, 0.2) if n.endswith("weight") else p.normal_(0, 0.2)
+	g = torch.Generator().manual_seed(4)
+	hw, B = 6, 5
+	x0 = torch.randn(B, hw * hw, 64, generator=g).to(gpu).to(dtype)
+	dy = torch.randn(B, hw * hw, 64, generator=g).to(gpu).to(dtype)
+
+	def run(fused):
+		cvt_layers.FUSED_BLOCK = fused
+		try:
+			blk.zero_grad()
+			x = x0.clone().requires_grad_(True)
+			y, h, w = blk(x, hw, hw)
+			assert (h, w) == (hw, hw)
+			y.backward(dy)
+			return y.detach(), x.grad, {n: p.grad.clone() for n, p in blk.named_parameters()}
+		finally:
+			cvt_layers.FUSED_BLOCK = True
+	y1, dx1, g1 = run(True)
+	y0, dx0, g0 = run(False)
+	tol = 2e-5 if dtype == torch.float32 else 3e-2
+	assert relerr(y1, y0.double()) < tol and relerr(dx1, dx0.double()) < tol
+	for n in g0:
+		assert relerr(g1[n], g0[n].double()) < (tol if dtype == torch.float32 else 6e-2), n
+	assert blk._fusable()
+	blk.train()
+	blk.ff_dropout.p = 0.1  # an active dropout: the block runs module by module
+	assert not blk._fusable()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("mode", ["train", "eval"])
 def test_cvt_golden(gpu, mode, dtype):
 	"""CvT (conv token embedding + BatchNorm + conv-projection attention with Skv < Sq, down to a single key in stage 3)."""
