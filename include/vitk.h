@@ -127,6 +127,15 @@ typedef struct vitk_gemm_desc {
 } vitk_gemm_desc;
 
 int vitk_gemm(const vitk_gemm_desc* desc, void* stream);
+/* n independent products in one call: the same results as vitk_gemm(&descs[i], stream) for i = 0 .. n - 1 in any order, so
+ * no product may read or write another's C / a_colsum, and all descriptors are checked before anything is launched.  What it
+ * is for: the four weight gradients of one block of a small model (dW = dy^T x of layers/attention.py:28,47 and
+ * layers/transformers.py:46-54 at d_model 192: 4 ... 12 output tiles over tens of thousands of tokens) -- products with
+ * MN-major operands, float32 result and the SAME workspace pointer share one launch, in which K is cut into a quarter of the
+ * slices each would need alone (a quarter of the partial-tile traffic, one reduction launch instead of four).  Products the
+ * grouped kernel does not take run exactly as vitk_gemm runs them.  The reference has no counterpart (autograd issues one
+ * addmm per Linear). */
+int vitk_gemm_group(const vitk_gemm_desc* descs, int n, void* stream);
 /* Size of `workspace` that is enough for any problem on this device (a fixed number of 256x256 float32 tiles). */
 int64_t vitk_gemm_workspace_bytes(void);
 /* on != 0: the persistent GEMM kernels launch the FEWEST workgroups that finish a problem in the same number of rounds of
@@ -139,7 +148,7 @@ int vitk_gemm_leave_cus_free(int on);
 /* 1 if vitk_gemm would run this problem on the bf16 MFMA kernel, 0 if on the generic float32-MFMA kernel. */
 int vitk_gemm_uses_bf16_mfma(const vitk_gemm_desc* desc);
 /* Name of the kernel family the calling thread's last vitk_gemm launched ("gemm_bf16_p8_kernel", "gemm_bf16_p8w_kernel",
- * "gemm_bf16_t128_kernel", "gemm_bf16_256_kernel", "gemm_bf16_kernel", "gemm_generic_kernel"; "" before the first call): the
+ * "gemm_bf16_t128_kernel", "gemm_bf16_256_kernel", "gemm_bf16_kernel", "gemm_bf16_group_kernel", "gemm_generic_kernel"; "" before the first call): the
  * names a kernel trace shows, for reports that put measured launch times next to a profile.  No counterpart in the
  * reference (torch.nn.functional.linear picks its kernel out of sight, layers/transformers.py:46-54). */
 const char* vitk_gemm_last_kernel(void);

@@ -351,6 +351,40 @@ def test_weight_gradients_on_the_second_stream_are_the_same_gradients(gpu):
 	assert float((out[False][1] - out[True][1]).abs().max()) < 1e-6
 
 
+@pytest.mark.parametrize("variant", ["vit", "vit_layerscale", "cvt"])
+@pytest.mark.parametrize("flat", [False, True])
+def test_weight_gradients_launched_together_are_the_same_gradients(gpu, variant, flat, monkeypatch):
+	"""The weight-gradient products of a block leave in one grouped call at the end of its backward (ops.wgrad_group);
+	one launch per product gives the same gradients up to the float32 summation order.  Enough tokens (1088 / 4096 ...)
+	that the grouped kernel really takes them; flat: into the gradient sinks of a dp.FlatModel."""
+	from conftest import relerr
+	from vit_amd import dp, ops
+	monkeypatch.setattr(ops, "WGRAD_OVERLAP", False)
+	make, xshape = VARIANTS[variant]
+	g = torch.Generator().manual_seed(11)
+	x = torch.randn(64, *xshape[1:], generator=g).to(gpu)
+	y = torch.randint(0, 10, (64,), generator=g).to(gpu)
+	grads = {}
+	for grouped in (False, True):
+		monkeypatch.setattr(ops, "WGRAD_GROUP", grouped)
+		ops.clear_grad_sinks()
+		model = make(gpu)
+		trainer = dp.Trainer(model) if flat else None
+		if trainer is not None:
+			trainer.zero_grad()
+		before = ops.GROUP_CALLS
+		with torch.autocast("cuda", dtype=torch.bfloat16):
+			ops.cross_entropy(model(x), y).backward()
+		torch.cuda.synchronize()
+		assert (ops.GROUP_CALLS > before) == grouped
+		grads[grouped] = {n: p.grad.detach().double().cpu() for n, p in model.named_parameters()}
+		if trainer is not None:
+			trainer.close()
+		ops.clear_grad_sinks()
+	for n, gref in grads[False].items():
+		assert relerr(grads[True][n], gref) < 2e-5, n
+
+
 def test_weight_gradient_on_the_second_stream_outside_backward(gpu):
 	"""ops.linear_wgrad(overlap=True) called outside a backward pass joins the second stream before it returns."""
 	from vit_amd import ops

@@ -312,6 +312,76 @@ def test_wgrad_with_bias_grad(gpu, dtype, M, N, K):
 	assert relerr(c, 3.0 * (dyr.t() @ xr)) < tol
 
 
+GROUPS = {
+	# (tokens, dy width, x width, bias gradient, accumulate): the four weight gradients of a block
+	"vit_tiny_block": [(33280, 576, 192, False, True), (33280, 192, 192, True, True), (33280, 768, 192, True, True), (33280, 192, 768, True, True)],
+	"cvt_stage1_block": [(65536, 192, 64, True, True), (65536, 64, 64, True, False), (65536, 256, 64, True, True), (65536, 64, 256, True, False)],
+	"cvt_stage3_block": [(4096, 1152, 384, True, True), (4096, 384, 384, True, True), (4096, 1536, 384, True, True), (4096, 384, 1536, True, True)],
+	# token counts that differ (one K slice for the short one), ragged widths, more products than one launch takes
+	"mixed_lengths": [(20000, 200, 136, True, True), (1024, 72, 264, True, False), (33280, 192, 576, False, False), (2048, 64, 64, True, True)],
+	"twelve": [(8192 + 64 * i, 64 + 8 * i, 192, i % 2 == 0, i % 3 != 0) for i in range(12)],
+	# products the grouped kernel does not take ride along (large tiles; few rows; float32 operands are a separate case below)
+	"with_others": [(33280, 192, 192, True, True), (197 * 64, 2304, 768, True, True), (16384, 192, 576, True, False), (512, 10, 192, True, True)],
+}
+
+
+@pytest.mark.parametrize("name", sorted(GROUPS))
+def test_gemm_group_matches_separate_launches(gpu, name):
+	"""vitk_gemm_group: several weight-gradient products (dW = dy^T x, db = column sums of dy) in one call give what one
+	vitk_gemm per product gives (float32 results, so only the summation order differs) and what float64 gives."""
+	import vit_amd._lib as L
+	from vit_amd import ops
+	dtype = torch.bfloat16
+	probs = []
+	for i, (M, N, K, bias, acc) in enumerate(GROUPS[name]):
+		dy, dyr = rnd((M, N), dtype, gpu, seed=10 + i)
+		x, xr = rnd((M, K), dtype, gpu, seed=50 + i)
+		probs.append((dy, x, dyr, xr, bias, acc))
+	start = 0.5  # what the accumulating products add into
+	def run(hold):
+		outs = []
+		for dy, x, _, _, bias, acc in probs:
+			(M, N), K = dy.shape, x.shape[1]
+			dw = torch.full((N, K), start, dtype=torch.float32, device=gpu) if acc else torch.full((N, K), float("nan"), dtype=torch.float32, device=gpu)
+			db = torch.full((N,), start, dtype=torch.float32, device=gpu) if bias else None
+			ops.gemm(dy, x, dw, N, K, M, N, K, K, a_layout=L.MN_MAJOR, b_layout=L.MN_MAJOR, a_colsum=db, accumulate=acc, hold=hold)
+			outs.append((dw, db))
+		return outs
+	single = run(None)
+	held = []
+	grouped = run(held)
+	assert len(held) == len(probs)
+	descs = (L.GemmDesc * len(held))(*[d for d, _ in held])
+	L.check(L.load().vitk_gemm_group(descs, len(held), L.stream()))
+	if name in ("vit_tiny_block", "cvt_stage1_block", "cvt_stage3_block", "mixed_lengths", "twelve"):
+		assert L.load().vitk_gemm_last_kernel().decode() == "gemm_bf16_group_kernel"
+	for (dw1, db1), (dwg, dbg), (dy, x, dyr, xr, bias, acc) in zip(single, grouped, probs):
+		ref = dyr.t() @ xr + (start if acc else 0.0)
+		assert relerr(dwg, ref) < 1e-3
+		assert relerr(dwg, dw1.double().cpu()) < 1e-5
+		if bias:
+			assert relerr(dbg, dyr.sum(0) + start) < 1e-3
+			assert relerr(dbg, db1.double().cpu()) < 1e-5
+	# nothing to do, one product, float32 operands (not the grouped kernel's): all through the same entry point
+	L.check(L.load().vitk_gemm_group(None, 0, L.stream()))
+	a, ar = rnd((300, 72), torch.float32, gpu, seed=3)
+	b, br = rnd((300, 130), torch.float32, gpu, seed=4)
+	held = []
+	c = torch.empty((72, 130), dtype=torch.float32, device=gpu)
+	ops.gemm(a, b, c, 72, 130, 300, 72, 130, 130, a_layout=L.MN_MAJOR, b_layout=L.MN_MAJOR, hold=held)
+	L.check(L.load().vitk_gemm_group((L.GemmDesc * 1)(held[0][0]), 1, L.stream()))
+	assert relerr(c, ar.t() @ br) < 1e-4
+	# a bad descriptor anywhere in the list: an error, and nothing is launched
+	held = []
+	c2 = torch.zeros((72, 130), dtype=torch.float32, device=gpu)
+	ops.gemm(a, b, c2, 72, 130, 300, 72, 130, 130, a_layout=L.MN_MAJOR, b_layout=L.MN_MAJOR, hold=held)
+	ops.gemm(a, b, c2, 72, 130, 300, 72, 130, 130, a_layout=L.MN_MAJOR, b_layout=L.MN_MAJOR, hold=held)
+	held[1][0].ldc = 1
+	assert L.load().vitk_gemm_group((L.GemmDesc * 2)(held[0][0], held[1][0]), 2, L.stream()) != 0
+	torch.cuda.synchronize()
+	assert float(c2.abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("B,C,HW,P", [(3, 3, 32, 8), (2, 3, 224, 14), (5, 1, 48, 6), (2, 2, 12, 2), (1, 3, 30, 10)])
 def test_patchify_kernels(gpu, dtype, B, C, HW, P):

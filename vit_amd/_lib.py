@@ -47,6 +47,7 @@ SIGNATURES = {
 	"vitk_strerror": [I],
 	"vitk_version": [],
 	"vitk_gemm": [POINTER(GemmDesc), P],
+	"vitk_gemm_group": [POINTER(GemmDesc), c_int, P],
 	"vitk_gemm_uses_bf16_mfma": [POINTER(GemmDesc)],
 	"vitk_gemm_last_kernel": [],
 	"vitk_gemm_workspace_bytes": [],

@@ -159,9 +159,9 @@ __device__ __forceinline__ void store_frag(const BfArgs& a, int64_t m, int64_t n
 	}
 }
 
+// One 128 x 128 output tile over one K slice: workgroup `wg_in` of the problem's tiles_m * tiles_n, K slice `split`.
 template <int ALAYOUT, int BLAYOUT, bool PATCH, typename TOUT>
-__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(BfArgs a) {
-	extern __shared__ __attribute__((aligned(16))) char smem[];
+__device__ __forceinline__ void gemm_bf16_tile(BfArgs& a, char* smem, const int wg_in, const int split) {
 	gemm_dev_enter(a.g);
 	const GemmDev& g = a.g;
 	const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -170,7 +170,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(BfArgs a) {
 	// XCD-aware, bijective remap of the linear workgroup id, then grouped (8 tile-rows) raster so that
 	// the workgroups sharing an XCD's L2 work on neighbouring tiles.
 	const int nwg = a.tiles_m * a.tiles_n;
-	int wg = blockIdx.x;
+	int wg = wg_in;
 	{
 		const int q = nwg >> 3, r = nwg & 7, xcd = wg & 7, idx = wg >> 3;
 		wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
@@ -184,7 +184,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(BfArgs a) {
 	const int tn = (wg % per_group) / gsz;
 	const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
 
-	const int k_begin = blockIdx.y * a.k_per_split;
+	const int k_begin = split * a.k_per_split;
 	const int k_end = min((int)g.K, k_begin + a.k_per_split);
 	const int nt = (k_end - k_begin + BK - 1) / BK;
 
@@ -297,7 +297,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(BfArgs a) {
 				float sum = 0.f;
 #pragma unroll
 				for (int r = 0; r < 16; ++r) sum += ct[r * 128 + tid];
-				if (a.cs_partials != nullptr) a.cs_partials[(int64_t)blockIdx.y * g.M + m0 + tid] = sum;
+				if (a.cs_partials != nullptr) a.cs_partials[(int64_t)split * g.M + m0 + tid] = sum;
 				else if (a.splits > 1) atomicAdd(a.a_colsum + m0 + tid, sum);
 				else a.a_colsum[m0 + tid] += sum;  // the only workgroup that owns these rows
 			}
@@ -314,7 +314,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(BfArgs a) {
 		// K-split partial tile into scratch, row-major 128 x 128 (512 contiguous bytes per row); split_reduce128_kernel
 		// adds the slices up: deterministic, and no float atomics (atomics of many workgroups on one address run one
 		// after the other at the memory side, about 0.2 us each)
-		float* dst = a.partials + ((int64_t)blockIdx.y * nwg + (int64_t)tm * a.tiles_n + tn) * (BM * BN);
+		float* dst = a.partials + ((int64_t)split * nwg + (int64_t)tm * a.tiles_n + tn) * (BM * BN);
 		for (int it = 0; it < (BM * BN / 4) / 256; ++it) {
 			const int v = it * 256 + tid;
 			const int row = v >> 5, c4 = v & 31;
@@ -343,41 +343,76 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(BfArgs a) {
 	}
 }
 
-// C (+)= sum over the K slices of the partial tiles (blockIdx.y < ntile),
-// and a_colsum += sum over the slices of the partial column sums (blockIdx.y == ntile).
-__global__ __launch_bounds__(256) void split_reduce128_kernel(const float* __restrict__ partials, float* __restrict__ C, int64_t M, int64_t N, int64_t ldc,
-	int tiles_n, int ntile, int splits, int accumulate, int vec4, const float* __restrict__ cs_partials, float* a_colsum) {
-	if ((int)blockIdx.y == ntile) {
-		if (cs_partials == nullptr) return;
-		for (int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x; m < M; m += (int64_t)gridDim.x * 256) {
+template <int ALAYOUT, int BLAYOUT, bool PATCH, typename TOUT>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(BfArgs a) {
+	extern __shared__ __attribute__((aligned(16))) char smem[];
+	gemm_bf16_tile<ALAYOUT, BLAYOUT, PATCH, TOUT>(a, smem, blockIdx.x, blockIdx.y);
+}
+
+// Several independent weight-gradient products (MN-major x MN-major, float32 result, K split through scratch) in one
+// launch: a block of a small model has four of them, each too small to fill the chip without cutting K so finely that
+// the partial tiles cost as much as the product.  Workgroups [first[i], first[i + 1]) belong to problem i, K slice by
+// K slice.
+constexpr int GROUP_MAX = 8;
+struct BfGroupArgs {
+	BfArgs p[GROUP_MAX];
+	int first[GROUP_MAX + 1];
+	int n;
+};
+static_assert(sizeof(BfGroupArgs) <= 4096, "kernel argument block");
+
+__global__ __launch_bounds__(256, 2) void gemm_bf16_group_kernel(BfGroupArgs ga) {
+	extern __shared__ __attribute__((aligned(16))) char smem[];
+	int gi = 0;
+	while (gi + 1 < ga.n && (int)blockIdx.x >= ga.first[gi + 1]) ++gi;
+	BfArgs a = ga.p[gi];
+	const int local = (int)blockIdx.x - ga.first[gi], nwg = a.tiles_m * a.tiles_n;
+	gemm_bf16_tile<VITK_MN_MAJOR, VITK_MN_MAJOR, false, float>(a, smem, local % nwg, local / nwg);
+}
+
+// C (+)= sum over the K slices of the partial tiles (block row `ty` < ntile),
+// and a_colsum += sum over the slices of the partial column sums (ty == ntile).
+struct ReduceItem {
+	const float* partials;
+	float* C;
+	int64_t M, N, ldc;
+	int tiles_n, ntile, splits, accumulate;
+	const float* cs_partials;
+	float* a_colsum;
+};
+
+__device__ __forceinline__ void split_reduce128_rows(const ReduceItem& r, const int ty) {
+	if (ty == r.ntile) {
+		if (r.cs_partials == nullptr) return;
+		for (int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x; m < r.M; m += (int64_t)gridDim.x * 256) {
 			float sum = 0.f;
-			for (int s0 = 0; s0 < splits; s0 += 16) {
+			for (int s0 = 0; s0 < r.splits; s0 += 16) {
 				float t[16];
 #pragma unroll
-				for (int u = 0; u < 16; ++u) t[u] = s0 + u < splits ? cs_partials[(int64_t)(s0 + u) * M + m] : 0.f;
+				for (int u = 0; u < 16; ++u) t[u] = s0 + u < r.splits ? r.cs_partials[(int64_t)(s0 + u) * r.M + m] : 0.f;
 #pragma unroll
 				for (int u = 0; u < 16; ++u) sum += t[u];
 			}
-			a_colsum[m] += sum;
+			r.a_colsum[m] += sum;
 		}
 		return;
 	}
 	// one thread per output element: four times the loads in flight of a 16-byte-per-thread walk, which is what this
 	// short, latency-bound kernel (tens of slices of a few tiles) needs; a wave still reads 256 contiguous bytes
-	const int tile = blockIdx.y;
+	const int tile = ty;
 	const int q = blockIdx.x * 256 + threadIdx.x;
 	const int row = q >> 7, col = q & 127;
-	const int64_t m = (int64_t)(tile / tiles_n) * BM + row;
-	const int64_t n = (int64_t)(tile % tiles_n) * BN + col;
-	if (m >= M || n >= N) return;
-	const float* src = partials + (int64_t)tile * (BM * BN) + q;
-	const int64_t step = (int64_t)ntile * (BM * BN);
+	const int64_t m = (int64_t)(tile / r.tiles_n) * BM + row;
+	const int64_t n = (int64_t)(tile % r.tiles_n) * BN + col;
+	if (m >= r.M || n >= r.N) return;
+	const float* src = r.partials + (int64_t)tile * (BM * BN) + q;
+	const int64_t step = (int64_t)r.ntile * (BM * BN);
 	// 16 slices requested before the first is used: the loop is a chain of memory round trips otherwise
 	float acc16[16];
 #pragma unroll
 	for (int u = 0; u < 16; ++u) acc16[u] = 0.f;
 	int s = 0;
-	for (; s + 15 < splits; s += 16) {
+	for (; s + 15 < r.splits; s += 16) {
 		float t[16];
 #pragma unroll
 		for (int u = 0; u < 16; ++u) t[u] = src[(int64_t)(s + u) * step];
@@ -387,7 +422,7 @@ __global__ __launch_bounds__(256) void split_reduce128_kernel(const float* __res
 	{
 		float t[16];
 #pragma unroll
-		for (int u = 0; u < 16; ++u) t[u] = s + u < splits ? src[(int64_t)(s + u) * step] : 0.f;
+		for (int u = 0; u < 16; ++u) t[u] = s + u < r.splits ? src[(int64_t)(s + u) * step] : 0.f;
 #pragma unroll
 		for (int u = 0; u < 16; ++u) acc16[u] += t[u];
 	}
@@ -396,8 +431,24 @@ __global__ __launch_bounds__(256) void split_reduce128_kernel(const float* __res
 #pragma unroll
 		for (int u = 0; u < w; ++u) acc16[u] += acc16[u + w];
 	const float v = acc16[0];
-	float* c = C + m * ldc + n;
-	*c = accumulate ? *c + v : v;
+	float* c = r.C + m * r.ldc + n;
+	*c = r.accumulate ? *c + v : v;
+}
+
+__global__ __launch_bounds__(256) void split_reduce128_kernel(ReduceItem r) { split_reduce128_rows(r, blockIdx.y); }
+
+// the same for the problems of a grouped launch: block rows [first[i], first[i + 1]) are problem i's ntile + 1 rows
+struct ReduceGroup {
+	ReduceItem p[GROUP_MAX];
+	int first[GROUP_MAX + 1];
+	int n;
+};
+
+__global__ __launch_bounds__(256) void split_reduce128_group_kernel(ReduceGroup rg) {
+	int gi = 0;
+	while (gi + 1 < rg.n && (int)blockIdx.y >= rg.first[gi + 1]) ++gi;
+	const ReduceItem r = rg.p[gi];
+	split_reduce128_rows(r, (int)blockIdx.y - rg.first[gi]);
 }
 
 template <int AL, int BL, bool PATCH>
@@ -470,23 +521,11 @@ int vitk_gemm_bf16(const vitk_gemm_desc& d, hipStream_t st, bool* colsum_done) {
 	return vitk_gemm_bf16_128(d, st, colsum_done);
 }
 
-int vitk_gemm_bf16_128(const vitk_gemm_desc& d, hipStream_t st, bool* colsum_done) {
-	vitk_last_gemm_kernel = "gemm_bf16_kernel";
-	BfArgs a{};
+// the fields of a 128 x 128 launch that do not depend on how K is cut
+static bool fill128(const vitk_gemm_desc& d, BfArgs& a) {
 	a.g = make_gemm_dev(d);
 	a.tiles_m = (int)vitk_cdiv(d.M, BM);
 	a.tiles_n = (int)vitk_cdiv(d.N, BN);
-	const int64_t tiles = (int64_t)a.tiles_m * a.tiles_n;
-	const int64_t ktiles = vitk_cdiv(d.K, BK);
-	// split-K only for the plain float32-output form (weight gradients): few output tiles, long K
-	a.splits = 1;
-	if (d.out_dtype == VITK_F32 && d.epilogue == VITK_EPI_NONE && d.bias == nullptr && d.tokens_per_image == 0 && tiles <= 256 && ktiles >= 16) {
-		int64_t s = std::min<int64_t>(512 / tiles, ktiles / 8);  // two workgroups per CU
-		a.splits = (int)std::max<int64_t>(1, std::min<int64_t>(s, 64));
-	}
-	const int64_t kt_per = vitk_cdiv(ktiles, a.splits);
-	a.k_per_split = (int)(kt_per * BK);
-	a.splits = (int)vitk_cdiv(ktiles, kt_per);
 	auto al16 = [](const void* p) { return p == nullptr || vitk_aligned(p, 16); };
 	a.vec4 = (d.N % 4 == 0) && (d.ldc % 4 == 0) && (d.ld_aux % 4 == 0) && (d.ld_out2 % 4 == 0) && al16(d.C) && al16(d.bias) && al16(d.gamma) && al16(d.pos) &&
 		al16(d.aux) && al16(d.out2);
@@ -494,6 +533,30 @@ int vitk_gemm_bf16_128(const vitk_gemm_desc& d, hipStream_t st, bool* colsum_don
 	static const bool no_fused_cs = getenv("VITK_NO_FUSED_COLSUM128") != nullptr;  // A-B switch
 	const bool fuse_colsum = !no_fused_cs && d.a_colsum != nullptr && d.a_layout == VITK_MN_MAJOR && d.patch_grid == 0;
 	if (fuse_colsum) a.a_colsum = d.a_colsum;
+	static const bool no_dma = getenv("VITK_NO_DMA128") != nullptr;  // A-B switch
+	a.dma = !no_dma && d.patch_grid == 0 && d.a_layout == VITK_K_MAJOR && d.b_layout == VITK_K_MAJOR && d.K % BK == 0 && d.M >= 1 && d.N >= 1;
+	return fuse_colsum;
+}
+
+static bool splits_k_128(const vitk_gemm_desc& d) {  // the plain float32-output form (weight gradients): few output tiles, long K
+	return d.out_dtype == VITK_F32 && d.epilogue == VITK_EPI_NONE && d.bias == nullptr && d.tokens_per_image == 0 &&
+		vitk_cdiv(d.M, BM) * vitk_cdiv(d.N, BN) <= 256 && vitk_cdiv(d.K, BK) >= 16;
+}
+
+int vitk_gemm_bf16_128(const vitk_gemm_desc& d, hipStream_t st, bool* colsum_done) {
+	vitk_last_gemm_kernel = "gemm_bf16_kernel";
+	BfArgs a{};
+	const bool fuse_colsum = fill128(d, a);
+	const int64_t tiles = (int64_t)a.tiles_m * a.tiles_n;
+	const int64_t ktiles = vitk_cdiv(d.K, BK);
+	a.splits = 1;
+	if (splits_k_128(d)) {
+		int64_t s = std::min<int64_t>(512 / tiles, ktiles / 8);  // two workgroups per CU
+		a.splits = (int)std::max<int64_t>(1, std::min<int64_t>(s, 64));
+	}
+	const int64_t kt_per = vitk_cdiv(ktiles, a.splits);
+	a.k_per_split = (int)(kt_per * BK);
+	a.splits = (int)vitk_cdiv(ktiles, kt_per);
 	if (a.splits > 1) {
 		const int64_t tile_bytes = (int64_t)a.splits * tiles * BM * BN * (int64_t)sizeof(float);
 		const int64_t need = tile_bytes + (fuse_colsum ? (int64_t)a.splits * d.M * (int64_t)sizeof(float) : 0);
@@ -506,8 +569,6 @@ int vitk_gemm_bf16_128(const vitk_gemm_desc& d, hipStream_t st, bool* colsum_don
 		hipError_t e = vitk_zero_f32_2d(reinterpret_cast<float*>(d.C), d.M, d.N, d.ldc, st);
 		if (e != hipSuccess) return VITK_ERR_HIP - (int)e;
 	}
-	static const bool no_dma = getenv("VITK_NO_DMA128") != nullptr;  // A-B switch
-	a.dma = !no_dma && d.patch_grid == 0 && d.a_layout == VITK_K_MAJOR && d.b_layout == VITK_K_MAJOR && d.K % BK == 0 && d.M >= 1 && d.N >= 1;
 	dim3 grid((unsigned)tiles, (unsigned)a.splits);
 	const bool patch = d.patch_grid > 0;
 	int rc;
@@ -517,10 +578,96 @@ int vitk_gemm_bf16_128(const vitk_gemm_desc& d, hipStream_t st, bool* colsum_don
 	else if (d.a_layout == VITK_MN_MAJOR && d.b_layout == VITK_MN_MAJOR) rc = launch<VITK_MN_MAJOR, VITK_MN_MAJOR, false>(a, d.out_dtype, grid, st);
 	else rc = launch<VITK_MN_MAJOR, VITK_K_MAJOR, false>(a, d.out_dtype, grid, st);
 	if (rc == VITK_OK && a.partials != nullptr) {
-		hipLaunchKernelGGL(split_reduce128_kernel, dim3(BM * BN / 256, (unsigned)tiles + 1), dim3(256), 0, st, a.partials, reinterpret_cast<float*>(d.C), d.M, d.N,
-			d.ldc, a.tiles_n, (int)tiles, a.splits, d.accumulate, a.vec4, a.cs_partials, d.a_colsum);
+		const ReduceItem r{a.partials, reinterpret_cast<float*>(d.C), d.M, d.N, d.ldc, a.tiles_n, (int)tiles, a.splits, d.accumulate, a.cs_partials, d.a_colsum};
+		hipLaunchKernelGGL(split_reduce128_kernel, dim3(BM * BN / 256, (unsigned)tiles + 1), dim3(256), 0, st, r);
 		VITK_CHECK_LAUNCH();
 	}
 	if (rc == VITK_OK && fuse_colsum && colsum_done != nullptr) *colsum_done = true;
 	return rc;
+}
+
+// A problem that vitk_gemm would run on the 128 x 128 kernel with K cut through the scratch buffer.
+bool vitk_gemm_bf16_group_ok(const vitk_gemm_desc& d) {
+	static const bool off = getenv("VITK_NO_GEMM_GROUP") != nullptr;  // A-B switch
+	if (off || d.in_dtype != VITK_BF16 || !vitk_gemm_bf16_ok(d)) return false;
+	if (vitk_gemm_bf16_256_ok(d)) {
+		// ... or on 256 x 256 tiles, but with so few tiles and so short a K that its launch would leave more than half of the CUs
+		// idle (384 x 384 ... 1536 x 384 over 4096 tokens: 4 ... 12 tiles x 8 slices)
+		static const bool starved_off = getenv("VITK_NO_GROUP_STARVED") != nullptr;  // A-B switch
+		const int64_t t256 = vitk_cdiv(d.M, 256) * vitk_cdiv(d.N, 256), kt = d.K / BK;
+		const int64_t s256 = std::max<int64_t>(1, std::min<int64_t>(256 / t256, kt / 8));  // as vitk_gemm_bf16_256 cuts K
+		if (starved_off || t256 * s256 > 128) return false;
+	}
+	if (d.a_layout != VITK_MN_MAJOR || d.b_layout != VITK_MN_MAJOR || d.patch_grid > 0 || !splits_k_128(d)) return false;
+	return d.workspace != nullptr && vitk_aligned(d.workspace, 16);
+}
+
+int vitk_gemm_group_max() { return GROUP_MAX; }
+
+// n <= GROUP_MAX independent problems, each vitk_gemm_bf16_group_ok and all with the same scratch buffer, as one launch plus
+// one reduction launch.  VITK_ERR_UNSUPPORTED (nothing launched): the scratch buffer is too small.
+int vitk_gemm_bf16_group128(const vitk_gemm_desc* const* ds, int n, hipStream_t st) {
+	if (n < 1 || n > GROUP_MAX) return VITK_ERR_UNSUPPORTED;
+	BfGroupArgs ga{};
+	bool fused[GROUP_MAX];
+	int64_t tiles[GROUP_MAX], ktiles[GROUP_MAX], work = 0;
+	for (int i = 0; i < n; ++i) {
+		fused[i] = fill128(*ds[i], ga.p[i]);
+		if (ds[i]->a_colsum != nullptr && !fused[i]) return VITK_ERR_UNSUPPORTED;
+		tiles[i] = (int64_t)ga.p[i].tiles_m * ga.p[i].tiles_n;
+		ktiles[i] = vitk_cdiv(ds[i]->K, BK);
+		work += tiles[i] * ktiles[i];
+	}
+	// one K-slice length for all problems (every workgroup then has the same amount of work), the shortest with which the
+	// launch fits the chip at two workgroups per CU and no problem has more than 64 slices
+	int64_t kt_per = std::max<int64_t>(8, vitk_cdiv(work, 512));
+	for (;; ++kt_per) {
+		int64_t wgs = 0, most = 0;
+		for (int i = 0; i < n; ++i) {
+			const int64_t s = vitk_cdiv(ktiles[i], kt_per);
+			wgs += tiles[i] * s;
+			most = std::max(most, s);
+		}
+		if (wgs <= 512 && most <= 64) break;
+	}
+	ReduceGroup rg{};
+	int64_t used = 0;  // bytes of the scratch buffer
+	int wg0 = 0, row0 = 0;
+	for (int i = 0; i < n; ++i) {
+		const vitk_gemm_desc& d = *ds[i];
+		BfArgs& a = ga.p[i];
+		a.splits = (int)vitk_cdiv(ktiles[i], kt_per);
+		a.k_per_split = (int)(kt_per * BK);
+		ga.first[i] = wg0;
+		wg0 += (int)(tiles[i] * a.splits);
+		if (a.splits == 1) continue;  // (stores its result itself)
+		a.partials = reinterpret_cast<float*>(reinterpret_cast<char*>(d.workspace) + used);
+		used += (int64_t)a.splits * tiles[i] * BM * BN * (int64_t)sizeof(float);
+		if (fused[i]) {
+			a.cs_partials = reinterpret_cast<float*>(reinterpret_cast<char*>(d.workspace) + used);
+			used += vitk_cdiv((int64_t)a.splits * d.M * (int64_t)sizeof(float), 256) * 256;
+		}
+		rg.p[rg.n] = ReduceItem{a.partials, reinterpret_cast<float*>(d.C), d.M, d.N, d.ldc, a.tiles_n, (int)tiles[i], a.splits, d.accumulate, a.cs_partials, d.a_colsum};
+		rg.first[rg.n] = row0;
+		row0 += (int)tiles[i] + 1;
+		++rg.n;
+	}
+	ga.first[n] = wg0;
+	ga.n = n;
+	rg.first[rg.n] = row0;
+	if (used > ds[0]->workspace_bytes) return VITK_ERR_UNSUPPORTED;
+	vitk_last_gemm_kernel = "gemm_bf16_group_kernel";
+	static bool attr_set = false;
+	if (!attr_set) {
+		hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
+		if (e != hipSuccess) return VITK_ERR_HIP - (int)e;
+		attr_set = true;
+	}
+	hipLaunchKernelGGL(gemm_bf16_group_kernel, dim3((unsigned)wg0), dim3(256), LDS_BYTES, st, ga);
+	VITK_CHECK_LAUNCH();
+	if (rg.n > 0) {
+		hipLaunchKernelGGL(split_reduce128_group_kernel, dim3(BM * BN / 256, (unsigned)row0), dim3(256), 0, st, rg);
+		VITK_CHECK_LAUNCH();
+	}
+	return VITK_OK;
 }

@@ -191,6 +191,10 @@ int vitk_gemm_generic(const vitk_gemm_desc& d, hipStream_t st);
 int vitk_gemm_bf16(const vitk_gemm_desc& d, hipStream_t st, bool* colsum_done);
 bool vitk_gemm_bf16_ok(const vitk_gemm_desc& d);
 int vitk_gemm_bf16_128(const vitk_gemm_desc& d, hipStream_t st, bool* colsum_done = nullptr);  // the 128x128 kernel, whatever the shape
+// several weight-gradient-shaped products in one launch of the 128x128 kernel (K cut through one shared scratch buffer)
+bool vitk_gemm_bf16_group_ok(const vitk_gemm_desc& d);
+int vitk_gemm_group_max();
+int vitk_gemm_bf16_group128(const vitk_gemm_desc* const* ds, int n, hipStream_t st);
 bool vitk_gemm_bf16_256_ok(const vitk_gemm_desc& d);  // large-tile LDS-DMA kernel (needs K % 64 == 0, M, N >= 256)
 int vitk_gemm_bf16_256(const vitk_gemm_desc& d, hipStream_t st, bool* colsum_done);
 bool vitk_gemm_bf16_p8_ok(const vitk_gemm_desc& d);  // persistent 256x256 kernel with the deep operand pipeline (whole tiles, K-major x K-major, bf16 out)

@@ -129,9 +129,7 @@ int vitk_gemm_generic(const vitk_gemm_desc& d, hipStream_t st) {
 	return VITK_OK;
 }
 
-extern "C" int vitk_gemm(const vitk_gemm_desc* desc, void* stream) {
-	VITK_REQUIRE(desc != nullptr, VITK_ERR_NULL);
-	const vitk_gemm_desc& d = *desc;
+static int check_desc(const vitk_gemm_desc& d) {
 	VITK_REQUIRE(d.A && d.B && d.C, VITK_ERR_NULL);
 	VITK_REQUIRE(d.M > 0 && d.N > 0 && d.K > 0 && d.K < (1ll << 31) && d.N < (1ll << 31), VITK_ERR_SHAPE);
 	VITK_REQUIRE(d.a_layout == VITK_K_MAJOR || d.a_layout == VITK_MN_MAJOR, VITK_ERR_UNSUPPORTED);
@@ -161,6 +159,16 @@ extern "C" int vitk_gemm(const vitk_gemm_desc* desc, void* stream) {
 		VITK_REQUIRE(d.drop_p[i] >= 0.f && d.drop_p[i] < 1.f, VITK_ERR_SHAPE);
 		if (d.drop_p[i] > 0.f) VITK_REQUIRE(d.epilogue != VITK_EPI_NONE && d.tokens_per_image == 0 && !d.accumulate, VITK_ERR_UNSUPPORTED);
 	}
+	return VITK_OK;
+}
+
+extern "C" int vitk_gemm(const vitk_gemm_desc* desc, void* stream) {
+	VITK_REQUIRE(desc != nullptr, VITK_ERR_NULL);
+	const vitk_gemm_desc& d = *desc;
+	{
+		const int rc = check_desc(d);
+		if (rc != VITK_OK) return rc;
+	}
 	hipStream_t st = (hipStream_t)stream;
 	if (d.in_dtype == VITK_BF16 && vitk_gemm_bf16_ok(d)) {
 		bool colsum_done = false;
@@ -172,6 +180,44 @@ extern "C" int vitk_gemm(const vitk_gemm_desc* desc, void* stream) {
 	}
 	// the kernel that ran does not fuse the column sums of A: A is [K rows][M columns] here
 	return vitk_colsum(d.A, d.a_colsum, d.K, d.M, d.lda, 1, d.in_dtype, stream);
+}
+
+extern "C" int vitk_gemm_group(const vitk_gemm_desc* descs, int n, void* stream) {
+	VITK_REQUIRE(n >= 0, VITK_ERR_SHAPE);
+	if (n == 0) return VITK_OK;
+	VITK_REQUIRE(descs != nullptr, VITK_ERR_NULL);
+	for (int i = 0; i < n; ++i) {  // every descriptor is checked before anything is launched
+		const int rc = check_desc(descs[i]);
+		if (rc != VITK_OK) return rc;
+	}
+	// weight-gradient-shaped products that would each get a launch of the 128 x 128 K-split kernel and share one scratch
+	// buffer go out together, up to vitk_gemm_group_max() per launch; everything else one by one
+	const int cap = vitk_gemm_group_max();
+	const vitk_gemm_desc* batch[16];
+	int nb = 0;
+	auto flush = [&]() -> int {
+		int rc = nb >= 2 ? vitk_gemm_bf16_group128(batch, nb, (hipStream_t)stream) : VITK_ERR_UNSUPPORTED;
+		if (rc == VITK_ERR_UNSUPPORTED) {
+			rc = VITK_OK;
+			for (int j = 0; j < nb && rc == VITK_OK; ++j) rc = vitk_gemm(batch[j], stream);
+		}
+		nb = 0;
+		return rc;
+	};
+	for (int i = 0; i < n; ++i) {
+		const vitk_gemm_desc& d = descs[i];
+		if (vitk_gemm_bf16_group_ok(d) && (nb == 0 || d.workspace == batch[0]->workspace)) {
+			batch[nb++] = &d;
+			if (nb == cap) {
+				const int rc = flush();
+				if (rc != VITK_OK) return rc;
+			}
+			continue;
+		}
+		const int rc = vitk_gemm(&d, stream);
+		if (rc != VITK_OK) return rc;
+	}
+	return flush();
 }
 
 extern "C" const char* vitk_gemm_last_kernel(void) { return vitk_last_gemm_kernel; }

@@ -251,6 +251,9 @@ def _sink(p):
 
 def _sink_done(p, sink):
 	"""Autograd's return value for a parameter whose gradient was accumulated into its sink."""
+	if sink[1] is not None and _wgrad_held is not None:
+		_wgrad_held_done.append((p, sink))  # products into sinks are still held back: report behind their launch (wgrad_group)
+		return None
 	if sink[1] is not None:
 		lane = _wgrad_lanes.get(p.device.index) if p.is_cuda else None
 		if lane is not None and (lane.held or lane.hooked):
@@ -433,9 +436,11 @@ def join_wgrad_stream():
 
 
 def gemm(A, B, C, M, N, K, lda, ldb, ldc, a_layout=L.K_MAJOR, b_layout=L.K_MAJOR, bias=None, epilogue=L.EPI_NONE, act=L.ACT_NONE,
-		aux=None, ld_aux=0, out2=None, ld_out2=0, gamma=None, accumulate=False, patch=None, tokens_per_image=0, pos=None, a_colsum=None, workspace=True, drop=(), lead_rows=0):
+		aux=None, ld_aux=0, out2=None, ld_out2=0, gamma=None, accumulate=False, patch=None, tokens_per_image=0, pos=None, a_colsum=None, workspace=True, drop=(), lead_rows=0,
+		hold=None):
 	"""C[M,N] (+)= epilogue(sum_k A(m,k) B(n,k)); see include/vitk.h for the operand layouts.  drop: up to two (p, seed)
-	dropouts fused into the epilogue (entries with p == 0 are ignored)."""
+	dropouts fused into the epilogue (entries with p == 0 are ignored).  hold: a list that takes (descriptor, operands)
+	instead of a launch (see wgrad_group)."""
 	L.require_gpu(A, B, C)
 	d = L.GemmDesc()
 	d.A, d.B, d.C = A.data_ptr(), B.data_ptr(), C.data_ptr()
@@ -464,6 +469,9 @@ def gemm(A, B, C, M, N, K, lda, ldb, ldc, a_layout=L.K_MAJOR, b_layout=L.K_MAJOR
 	assert aux is None or aux.dtype == A.dtype
 	assert out2 is None or out2.dtype == C.dtype
 	lib = L.load()
+	if hold is not None:
+		hold.append((d, (A, B, C, a_colsum)))
+		return C
 	if GEMM_PROFILE is None:
 		L.check(lib.vitk_gemm(d, L.stream()))
 		return C
@@ -521,13 +529,14 @@ def linear_dgrad(dy, w, act=L.ACT_NONE, pre=None, out=None, drop=()):
 	return dx
 
 
-def linear_wgrad(dy, x, bias_grad=False, dw_out=None, db_out=None, overlap=False, after=None):
+def linear_wgrad(dy, x, bias_grad=False, dw_out=None, db_out=None, overlap=False, after=None, group=True):
 	"""dw[N, K] = dy.T @ x in float32.  With bias_grad also db[N] = column sums of dy, formed by the same kernel from
 	the dy tiles it stages anyway (or by a column-sum kernel after it, where the GEMM path that runs does not fuse
 	it): returns (dw, db).  dw_out / db_out: float32 buffers that the results are ADDED into instead (gradient
 	sinks); they are returned in place of fresh tensors.  overlap: the caller writes neither dy nor x afterwards, so a
 	large product whose results go to sinks only may run on the weight-gradient stream (joined at the end of backward),
-	there ordered behind the event `after` (wgrad_mark) if given, else behind the current stream."""
+	there ordered behind the event `after` (wgrad_mark) if given, else behind the current stream.  group=False: the caller
+	reads the result before its wgrad_group ends, so the product must not be held back."""
 	M, N = dy.shape
 	K = x.shape[1]
 	assert x.shape[0] == M and dy.stride(1) == 1 and x.stride(1) == 1
@@ -538,9 +547,53 @@ def linear_wgrad(dy, x, bias_grad=False, dw_out=None, db_out=None, overlap=False
 	lane = None
 	if overlap and dw_out is not None and (db_out is not None or not bias_grad):
 		lane = _wgrad_lane(dy, 2.0 * M * N * K)
+	hold = None
+	if group and lane is None and _wgrad_held is not None and dy.dtype == torch.bfloat16 and 2.0 * M * N * K < WGRAD_GROUP_MAX_FLOPS:
+		hold = _wgrad_held
 	with (lane.section(after, dy, x) if lane is not None else contextlib.nullcontext()):
-		gemm(dy, x, dw, N, K, M, dy.stride(0), x.stride(0), K, a_layout=L.MN_MAJOR, b_layout=L.MN_MAJOR, a_colsum=db, accumulate=dw_out is not None)
+		gemm(dy, x, dw, N, K, M, dy.stride(0), x.stride(0), K, a_layout=L.MN_MAJOR, b_layout=L.MN_MAJOR, a_colsum=db, accumulate=dw_out is not None, hold=hold)
 	return (dw, db) if bias_grad else dw
+
+
+# The weight-gradient products of one block of a SMALL model (d_model 192: 4 ... 12 output tiles over tens of thousands of
+# tokens each) cannot fill the chip one at a time without cutting K so finely that writing and re-reading the partial
+# tiles costs as much as the product.  A block's backward therefore holds them back and hands all of them to the library
+# in one call at its end (vitk_gemm_group: one launch, K cut a quarter as finely, one reduction launch).  Large products
+# (the ones that go to the second stream) are never held.
+WGRAD_GROUP = os.environ.get("VITK_WGRAD_GROUP", "1") != "0"
+WGRAD_GROUP_MAX_FLOPS = 2e10  # (the size from which a product alone fills the chip; equals the second stream's lower bound)
+GROUP_CALLS = 0  # grouped calls made so far (tests, diagnostics)
+_wgrad_held = None  # list of (descriptor, operands) while a block collects
+_wgrad_held_done = []  # (parameter, sink) whose "written" reports wait for the held products to be launched
+
+
+@contextlib.contextmanager
+def wgrad_group():
+	"""Small weight-gradient products issued inside (linear_wgrad calls that would run on the current stream) are launched
+	together on leaving.  Their operands and results must not be touched inside after the call that issued them, and the
+	current stream must be the same on leaving."""
+	global _wgrad_held, GROUP_CALLS
+	if _wgrad_held is not None or not WGRAD_GROUP or GEMM_PROFILE is not None:
+		yield
+		return
+	_wgrad_held = []
+	try:
+		yield
+	except BaseException:
+		_wgrad_held = None
+		_wgrad_held_done.clear()
+		raise
+	held, _wgrad_held = _wgrad_held, None
+	if len(held) == 1:
+		L.check(L.load().vitk_gemm(held[0][0], L.stream()))
+	elif held:
+		descs = (L.GemmDesc * len(held))(*[d for d, _ in held])
+		L.check(L.load().vitk_gemm_group(descs, len(held), L.stream()))
+		GROUP_CALLS += 1
+	reports = list(_wgrad_held_done)
+	_wgrad_held_done.clear()
+	for p, sink in reports:
+		_sink_done(p, sink)
 
 
 def colsum(x):
@@ -825,8 +878,9 @@ class FeedForwardFn(torch.autograd.Function):
 		xshape, xdtype, b1, b2, act, gated, dt = ctx.meta
 		dy2 = _flat(cast(dy, dt))
 		sk = _Sinks(w1=w1, b1=b1, w2=w2, b2=b2)
-		dx, dw1, db1, dw2, db2 = _ffn_backward(dy2, x2, u, a, weight_as(w1, dt), weight_as(w2, dt), act, gated, ctx.needs_input_grad[0],
-			outs=(sk.buf("w1"), sk.buf("b1"), sk.buf("w2"), sk.buf("b2")))
+		with wgrad_group():
+			dx, dw1, db1, dw2, db2 = _ffn_backward(dy2, x2, u, a, weight_as(w1, dt), weight_as(w2, dt), act, gated, ctx.needs_input_grad[0],
+				outs=(sk.buf("w1"), sk.buf("b1"), sk.buf("w2"), sk.buf("b2")))
 		if dx is not None:
 			dx = dx.reshape(xshape)
 			if dx.dtype != xdtype:
@@ -878,8 +932,9 @@ class MHAFn(torch.autograd.Function):
 		(B, S, d), xdtype, bo, n_head, dt, drop = ctx.meta
 		dy2 = _flat(cast(dy, dt))
 		sk = _Sinks(wqkv=wqkv, wo=wo, bo=bo)
-		dx, dwqkv, dwo, dbo = _mha_backward(dy2, x2, qkv, o, lse, weight_as(wqkv, dt), weight_as(wo, dt), B, S, n_head, ctx.needs_input_grad[0],
-			outs=(sk.buf("wqkv"), sk.buf("wo"), sk.buf("bo")), drop=drop)
+		with wgrad_group():
+			dx, dwqkv, dwo, dbo = _mha_backward(dy2, x2, qkv, o, lse, weight_as(wqkv, dt), weight_as(wo, dt), B, S, n_head, ctx.needs_input_grad[0],
+				outs=(sk.buf("wqkv"), sk.buf("wo"), sk.buf("bo")), drop=drop)
 		if dx is not None:
 			dx = dx.reshape(B, S, d)
 			if dx.dtype != xdtype:
@@ -937,29 +992,30 @@ class ViTBlockFn(torch.autograd.Function):
 		d_attn, d_a, d_f1, d_f2, d_b = (dr.get(k, off) for k in ("attn", "a", "f1", "f2", "b"))
 		wqkv_c, wo_c, w1_c, w2_c = (weight_as(t, dt) for t in (wqkv, wo, w1, w2))
 		dx2 = _flat(cast(dy, dt))
-		# feed-forward branch
-		if ls2 is not None:
-			dbr2, dls2 = layerscale_bwd(dx2, br2, f32(ls2))
-		elif d_f2[0] > 0.0 or d_b[0] > 0.0:
-			m1, m2 = (d_f2, d_b) if d_f2[0] > 0.0 else (d_b, off)
-			dbr2, dls2 = dropout_add(dx2, None, m1[0], m1[1], m2[0], m2[1]), None
-		else:
-			dbr2, dls2 = dx2, None
 		# parameters with a registered gradient sink get their gradients accumulated in place by the kernels
 		sk = {n: _sink(t) for n, t in (("n1w", n1w), ("n1b", n1b), ("wqkv", wqkv), ("wo", wo), ("bo", bo), ("n2w", n2w), ("n2b", n2b), ("w1", w1), ("b1", b1),
 			("w2", w2), ("b2", b2))}
 		buf = {n: (v[0] if v is not None else None) for n, v in sk.items()}
-		dn2, dw1, db1, dw2, db2 = _ffn_backward(dbr2, n2, u, a, w1_c, w2_c, act, gated, outs=(buf["w1"], buf["b1"], buf["w2"], buf["b2"]), drop1=d_f1)
-		dx1, dn2w, dn2b = norm_bwd(dn2, x1, f32(n2w), mean2, rstd2, kind, unit_offset, dres=dx2, dw_out=buf["n2w"], db_out=buf["n2b"])
-		# attention branch
-		if ls1 is not None:
-			dbr1, dls1 = layerscale_bwd(dx1, br1, f32(ls1))
-		elif d_a[0] > 0.0:
-			dbr1, dls1 = dropout_add(dx1, None, d_a[0], d_a[1]), None
-		else:
-			dbr1, dls1 = dx1, None
-		dn1, dwqkv, dwo, dbo = _mha_backward(dbr1, n1, qkv, o, lse, wqkv_c, wo_c, B, S, n_head, outs=(buf["wqkv"], buf["wo"], buf["bo"]), drop=d_attn)
-		dx0, dn1w, dn1b = norm_bwd(dn1, x0, f32(n1w), mean1, rstd1, kind, unit_offset, dres=dx1, dw_out=buf["n1w"], db_out=buf["n1b"])
+		with wgrad_group():  # (a small model's four weight-gradient products leave together at the end)
+			# feed-forward branch
+			if ls2 is not None:
+				dbr2, dls2 = layerscale_bwd(dx2, br2, f32(ls2))
+			elif d_f2[0] > 0.0 or d_b[0] > 0.0:
+				m1, m2 = (d_f2, d_b) if d_f2[0] > 0.0 else (d_b, off)
+				dbr2, dls2 = dropout_add(dx2, None, m1[0], m1[1], m2[0], m2[1]), None
+			else:
+				dbr2, dls2 = dx2, None
+			dn2, dw1, db1, dw2, db2 = _ffn_backward(dbr2, n2, u, a, w1_c, w2_c, act, gated, outs=(buf["w1"], buf["b1"], buf["w2"], buf["b2"]), drop1=d_f1)
+			dx1, dn2w, dn2b = norm_bwd(dn2, x1, f32(n2w), mean2, rstd2, kind, unit_offset, dres=dx2, dw_out=buf["n2w"], db_out=buf["n2b"])
+			# attention branch
+			if ls1 is not None:
+				dbr1, dls1 = layerscale_bwd(dx1, br1, f32(ls1))
+			elif d_a[0] > 0.0:
+				dbr1, dls1 = dropout_add(dx1, None, d_a[0], d_a[1]), None
+			else:
+				dbr1, dls1 = dx1, None
+			dn1, dwqkv, dwo, dbo = _mha_backward(dbr1, n1, qkv, o, lse, wqkv_c, wo_c, B, S, n_head, outs=(buf["wqkv"], buf["wo"], buf["bo"]), drop=d_attn)
+			dx0, dn1w, dn1b = norm_bwd(dn1, x0, f32(n1w), mean1, rstd1, kind, unit_offset, dres=dx1, dw_out=buf["n1w"], db_out=buf["n1b"])
 		dx0 = dx0.reshape(B, S, d)
 		if dx0.dtype != xdtype:
 			dx0 = cast(dx0, xdtype)
@@ -1593,7 +1649,8 @@ def _conv_attn_backward(dy2, x2, qkv, kv1, o, lse, wqkv, ckv, wo, geom, Skv, sk,
 	# a gradient whose sinks are apart (or absent) are added by hand (or handed to autograd)
 	w_sink = _joint([sk.buf("wq"), sk.buf("wk"), sk.buf("wv")])
 	b_sink = _joint([sk.buf("bq"), sk.buf("bk"), sk.buf("bv")])
-	dw3, db3 = linear_wgrad(dqkv, x2, bias_grad=True, dw_out=w_sink, db_out=b_sink)
+	by_hand = (w_sink is None and any(sk.buf(n) is not None for n in ("wq", "wk", "wv"))) or (b_sink is None and any(sk.buf(n) is not None for n in ("bq", "bk", "bv")))
+	dw3, db3 = linear_wgrad(dqkv, x2, bias_grad=True, dw_out=w_sink, db_out=b_sink, group=not by_hand)
 
 	def hand_out(names, joint_sink, g3):
 		out = []
@@ -1647,7 +1704,8 @@ class ConvAttentionFn(torch.autograd.Function):
 		(Bn, S, C), xdtype, (bq, bk, bv, bo), geom, dt, Skv, drop = ctx.meta
 		dy2 = _flat(cast(dy, dt))
 		sk = _Sinks(wq=wq, bq=bq, wk=wk, bk=bk, wv=wv, bv=bv, wo=wo, bo=bo)
-		dx, gw, gb, dckv, gwo, gbo = _conv_attn_backward(dy2, x2, qkv, kv1, o, lse, wqkv, ckv, weight_as(wo, dt), geom, Skv, sk, ctx.needs_input_grad[0], drop)
+		with wgrad_group():
+			dx, gw, gb, dckv, gwo, gbo = _conv_attn_backward(dy2, x2, qkv, kv1, o, lse, wqkv, ckv, weight_as(wo, dt), geom, Skv, sk, ctx.needs_input_grad[0], drop)
 		if dx is not None:
 			dx = dx.reshape(Bn, S, C)
 			if dx.dtype != xdtype:
@@ -1702,15 +1760,16 @@ class CvTBlockFn(torch.autograd.Function):
 		kind, eps, unit_offset, H, W, n_head, ks, stride, pad, act, gated = cfg
 		sk = _Sinks(n1w=n1w, n1b=n1b, wq=wq, bq=bq, wk=wk, bk=bk, wv=wv, bv=bv, wo=wo, bo=bo, n2w=n2w, n2b=n2b, w1=w1, b1=b1, w2=w2, b2=b2)
 		dx2 = _flat(cast(dy, dt))
-		# feed-forward branch
-		dbr2, dls2 = layerscale_bwd(dx2, br2, f32(ls2)) if ls2 is not None else (dx2, None)
-		dn2, dw1, db1, dw2, db2 = _ffn_backward(dbr2, n2, u, a, weight_as(w1, dt), weight_as(w2, dt), act, gated,
-			outs=(sk.buf("w1"), sk.buf("b1"), sk.buf("w2"), sk.buf("b2")))
-		dx1, dn2w, dn2b = norm_bwd(dn2, x1, f32(n2w), mean2, rstd2, kind, unit_offset, dres=dx2, dw_out=sk.buf("n2w"), db_out=sk.buf("n2b"))
-		# attention branch
-		dbr1, dls1 = layerscale_bwd(dx1, br1, f32(ls1)) if ls1 is not None else (dx1, None)
-		dn1, gw, gb, dckv, gwo, gbo = _conv_attn_backward(dbr1, n1, qkv, kv1, o, lse, wqkv, ckv, weight_as(wo, dt), geom, Skv, sk)
-		dx0, dn1w, dn1b = norm_bwd(dn1, x0, f32(n1w), mean1, rstd1, kind, unit_offset, dres=dx1, dw_out=sk.buf("n1w"), db_out=sk.buf("n1b"))
+		with wgrad_group():  # (the block's four weight-gradient products leave together at the end)
+			# feed-forward branch
+			dbr2, dls2 = layerscale_bwd(dx2, br2, f32(ls2)) if ls2 is not None else (dx2, None)
+			dn2, dw1, db1, dw2, db2 = _ffn_backward(dbr2, n2, u, a, weight_as(w1, dt), weight_as(w2, dt), act, gated,
+				outs=(sk.buf("w1"), sk.buf("b1"), sk.buf("w2"), sk.buf("b2")))
+			dx1, dn2w, dn2b = norm_bwd(dn2, x1, f32(n2w), mean2, rstd2, kind, unit_offset, dres=dx2, dw_out=sk.buf("n2w"), db_out=sk.buf("n2b"))
+			# attention branch
+			dbr1, dls1 = layerscale_bwd(dx1, br1, f32(ls1)) if ls1 is not None else (dx1, None)
+			dn1, gw, gb, dckv, gwo, gbo = _conv_attn_backward(dbr1, n1, qkv, kv1, o, lse, wqkv, ckv, weight_as(wo, dt), geom, Skv, sk)
+			dx0, dn1w, dn1b = norm_bwd(dn1, x0, f32(n1w), mean1, rstd1, kind, unit_offset, dres=dx1, dw_out=sk.buf("n1w"), db_out=sk.buf("n1b"))
 		dx0 = dx0.reshape(Bn, S, C)
 		if dx0.dtype != xdtype:
 			dx0 = cast(dx0, xdtype)
