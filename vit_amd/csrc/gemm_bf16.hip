@@ -121,7 +121,8 @@ struct BfArgs {
 	GemmDev g;
 	int tiles_m, tiles_n, splits, k_per_split;  // k_per_split is a multiple of BK
 	int vec4;                                    // epilogue may use 4-wide accesses
-	int dma;                                     // K-major x K-major, K % 64 == 0: operand tiles by LDS-DMA
+	int dma;                                     // K % 64 == 0: operand tiles by LDS-DMA; 1: K-major x K-major, 2: MN-major x MN-major
+	int cs_turns;                                // workgroups (tile columns) that take turns, K tile by K tile, at the column sums of their A tile
 	float* partials;                             // K split through scratch: [split][tile][128 x 128] partial tiles (else float atomics into C)
 	float* cs_partials;                          // [split][M] partial column sums of A (with partials and a_colsum)
 	float* a_colsum;                             // MN-major A: a_colsum[m] += sum_k A(m, k), formed from the staged A tiles
@@ -145,6 +146,40 @@ __device__ __forceinline__ void dma_tile_k(char* tile, const bf16_t* __restrict_
 	}
 }
 
+// The same for one [64 k][128 columns] MN-major operand tile (256-byte rows): 16 pieces of 4 k-rows, wave w takes pieces
+// 2 w, 2 w + 1, 2 w + 8, 2 w + 9, for all of which bit 3 of the row index is (w & 1): the unit swizzle of swz_mn is then one
+// loop-invariant lane offset.  Lane l lands at row l >> 4, physical 16-byte chunk l & 15 of its piece, so it fetches the
+// logical chunk that swz_mn puts there.  Columns past the operand's last re-read its last 8 (they only reach output rows /
+// columns that are never stored).
+__device__ __forceinline__ void dma_tile_mn(char* tile, const bf16_t* __restrict__ base, int64_t ld, int64_t mn0, int64_t mn_total, int k0, int wave, int lane) {
+	const int prow = lane >> 4, pchunk = lane & 15;
+	const int lchunk = (((pchunk >> 1) ^ (prow | ((wave & 1) << 2))) << 1) | (pchunk & 1);
+	int64_t col = mn0 + 8 * lchunk;
+	if (col > mn_total - 8) col = mn_total - 8;
+#pragma unroll
+	for (int j = 0; j < 4; ++j) {
+		const int piece = 2 * wave + (j & 1) + 8 * (j >> 1);
+		const bf16_t* src = base + (int64_t)(k0 + 4 * piece + prow) * ld + col;
+		__builtin_amdgcn_global_load_lds((gbl_void_p)src, (lds_void_p)(tile + piece * 1024), 16, 0, 0);
+	}
+}
+
+__device__ __forceinline__ uint32_t lds_addr(const char* p) { return (uint32_t)(uintptr_t)(lds_void_p)(void*)p; }
+// (inline asm: written as the builtin, the compiler waits vmcnt(0) in front of a transposing read, i.e. for the next
+// tile's LDS-DMA that was just issued)
+__device__ __forceinline__ void lds_read_tr(s16x4& dst, uint32_t addr, int offset) {
+	asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(offset));
+}
+__device__ __forceinline__ bf16x8 join8(s16x4 lo, s16x4 hi) {
+	union {
+		s16x4 h[2];
+		bf16x8 v;
+	} u;
+	u.h[0] = lo;
+	u.h[1] = hi;
+	return u.v;
+}
+
 template <typename TOUT>
 __device__ __forceinline__ void store_frag(const BfArgs& a, int64_t m, int64_t nb, f32x4 v) {
 	const GemmDev& g = a.g;
@@ -160,7 +195,7 @@ __device__ __forceinline__ void store_frag(const BfArgs& a, int64_t m, int64_t n
 }
 
 // One 128 x 128 output tile over one K slice: workgroup `wg_in` of the problem's tiles_m * tiles_n, K slice `split`.
-template <int ALAYOUT, int BLAYOUT, bool PATCH, typename TOUT>
+template <int ALAYOUT, int BLAYOUT, bool PATCH, typename TOUT, bool XCD_REMAP = true>
 __device__ __forceinline__ void gemm_bf16_tile(BfArgs& a, char* smem, const int wg_in, const int split) {
 	gemm_dev_enter(a.g);
 	const GemmDev& g = a.g;
@@ -171,7 +206,7 @@ __device__ __forceinline__ void gemm_bf16_tile(BfArgs& a, char* smem, const int 
 	// the workgroups sharing an XCD's L2 work on neighbouring tiles.
 	const int nwg = a.tiles_m * a.tiles_n;
 	int wg = wg_in;
-	{
+	if (XCD_REMAP) {
 		const int q = nwg >> 3, r = nwg & 7, xcd = wg & 7, idx = wg >> 3;
 		wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 	}
@@ -216,7 +251,7 @@ __device__ __forceinline__ void gemm_bf16_tile(BfArgs& a, char* smem, const int 
 	// 4 k rows per K tile through its registers anyway, so it adds them up on the way; the workgroups of the first tile
 	// column do it (all tile columns stage the same A).  Out-of-range pieces were read as zeros.
 	bool do_colsum = false;
-	if constexpr (ALAYOUT == VITK_MN_MAJOR) do_colsum = a.a_colsum != nullptr && tn == 0;
+	if constexpr (ALAYOUT == VITK_MN_MAJOR) do_colsum = a.a_colsum != nullptr && tn < a.cs_turns;
 	float csum[8];
 #pragma unroll
 	for (int e = 0; e < 8; ++e) csum[e] = 0.f;
@@ -233,9 +268,90 @@ __device__ __forceinline__ void gemm_bf16_tile(BfArgs& a, char* smem, const int 
 		}
 	};
 
-	bool by_dma = false;
-	if constexpr (ALAYOUT == VITK_K_MAJOR && BLAYOUT == VITK_K_MAJOR && !PATCH) by_dma = a.dma != 0;
-	if (by_dma) {
+	bool by_dma = false, by_dma_mn = false;
+	if constexpr (ALAYOUT == VITK_K_MAJOR && BLAYOUT == VITK_K_MAJOR && !PATCH) by_dma = a.dma == 1;
+	if constexpr (ALAYOUT == VITK_MN_MAJOR && BLAYOUT == VITK_MN_MAJOR && !PATCH) by_dma_mn = a.dma == 2;
+	float csum1 = 0.f;  // by_dma_mn: column tid & 127 of the A tile over k-rows 32 (tid >> 7) .. + 31, of the K tiles that are this workgroup's turn
+	if (by_dma_mn) {
+		// as below (one barrier per K tile), with both MN-major tiles staged by LDS-DMA and every LDS read issued as inline asm
+		const uint32_t lds0 = lds_addr(smem);
+		const int fg = lane >> 4, fq = (lane >> 2) & 3, fp = lane & 3;
+		const uint32_t a_lane = (uint32_t)(swz_mn(8 * fg + fq, (wm >> 3) + (fp >> 1)) + ((fp & 1) << 3));
+		const uint32_t b_lane = (uint32_t)(swz_mn(8 * fg + fq, (wn >> 3) + (fp >> 1)) + ((fp & 1) << 3));
+		const int cs_c = tid & 127, cs_r = tid >> 7;
+		dma_tile_mn(smem, A, g.lda, m0, g.M, k_begin, wave, lane);
+		dma_tile_mn(smem + TILE_BYTES, B, g.ldb, n0, g.N, k_begin, wave, lane);
+		for (int t = 0; t < nt; ++t) {
+			__syncthreads();
+			const uint32_t sa = lds0 + (t & 1) * STAGE_BYTES, sb = sa + TILE_BYTES;
+			if (t + 1 < nt) {
+				char* da = smem + ((t + 1) & 1) * STAGE_BYTES;
+				const int k0 = k_begin + (t + 1) * BK;
+				dma_tile_mn(da, A, g.lda, m0, g.M, k0, wave, lane);
+				dma_tile_mn(da + TILE_BYTES, B, g.ldb, n0, g.N, k0, wave, lane);
+			}
+			if (do_colsum && (k_begin / BK + t) % a.cs_turns == tn) {
+#pragma unroll
+				for (int b4 = 0; b4 < 4; ++b4) {
+					uint32_t v[8];
+#pragma unroll
+					for (int e = 0; e < 8; ++e) {
+						const int kr = 32 * cs_r + 8 * b4 + e;
+						const uint32_t ad = sa + (uint32_t)(swz_mn(kr, cs_c >> 3) + (cs_c & 7) * 2);
+						asm volatile("ds_read_u16 %0, %1" : "=v"(v[e]) : "v"(ad));
+					}
+					asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7])::"memory");
+#pragma unroll
+					for (int e = 0; e < 8; ++e) csum1 += __builtin_bit_cast(float, v[e] << 16);
+				}
+			}
+			s16x4 xa[4][2][2], xb[4][2][2];  // [fragment][k half][read]
+			// all 32 reads up front, k half 0 first; LDS reads return in order and the counter holds 15 at most, so "at most 15
+			// outstanding" means the first 17 have landed
+#pragma unroll
+			for (int j = 0; j < 4; ++j) {
+				lds_read_tr(xb[j][0][0], sb + (b_lane ^ (j << 5)), 0);
+				lds_read_tr(xb[j][0][1], sb + (b_lane ^ (j << 5)), 1024);
+			}
+#pragma unroll
+			for (int i = 0; i < 4; ++i) {
+				lds_read_tr(xa[i][0][0], sa + (a_lane ^ (i << 5)), 0);
+				lds_read_tr(xa[i][0][1], sa + (a_lane ^ (i << 5)), 1024);
+			}
+#pragma unroll
+			for (int j = 0; j < 4; ++j) {
+				lds_read_tr(xb[j][1][0], sb + (b_lane ^ (j << 5)), 8192);
+				lds_read_tr(xb[j][1][1], sb + (b_lane ^ (j << 5)), 8192 + 1024);
+			}
+#pragma unroll
+			for (int i = 0; i < 4; ++i) {
+				lds_read_tr(xa[i][1][0], sa + (a_lane ^ (i << 5)), 8192);
+				lds_read_tr(xa[i][1][1], sa + (a_lane ^ (i << 5)), 8192 + 1024);
+			}
+			asm volatile("s_waitcnt lgkmcnt(15)"
+						 : "+v"(xb[0][0][0]), "+v"(xb[0][0][1]), "+v"(xb[1][0][0]), "+v"(xb[1][0][1]), "+v"(xb[2][0][0]), "+v"(xb[2][0][1]), "+v"(xb[3][0][0]), "+v"(xb[3][0][1]),
+						   "+v"(xa[0][0][0]), "+v"(xa[0][0][1]), "+v"(xa[1][0][0]), "+v"(xa[1][0][1]), "+v"(xa[2][0][0]), "+v"(xa[2][0][1]), "+v"(xa[3][0][0]), "+v"(xa[3][0][1])
+						 :
+						 : "memory");
+#pragma unroll
+			for (int i = 0; i < 4; ++i)
+#pragma unroll
+				for (int j = 0; j < 4; ++j)
+					acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(join8(xb[j][0][0], xb[j][0][1]), join8(xa[i][0][0], xa[i][0][1]), acc[i][j], 0, 0, 0);
+			__builtin_amdgcn_sched_barrier(0);  // (the first half's MFMAs stay in front of the wait for the second half's reads)
+			asm volatile("s_waitcnt lgkmcnt(0)"
+						 : "+v"(xb[0][1][0]), "+v"(xb[0][1][1]), "+v"(xb[1][1][0]), "+v"(xb[1][1][1]), "+v"(xb[2][1][0]), "+v"(xb[2][1][1]), "+v"(xb[3][1][0]), "+v"(xb[3][1][1]),
+						   "+v"(xa[0][1][0]), "+v"(xa[0][1][1]), "+v"(xa[1][1][0]), "+v"(xa[1][1][1]), "+v"(xa[2][1][0]), "+v"(xa[2][1][1]), "+v"(xa[3][1][0]), "+v"(xa[3][1][1])
+						 :
+						 : "memory");
+#pragma unroll
+			for (int i = 0; i < 4; ++i)
+#pragma unroll
+				for (int j = 0; j < 4; ++j)
+					acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(join8(xb[j][1][0], xb[j][1][1]), join8(xa[i][1][0], xa[i][1][1]), acc[i][j], 0, 0, 0);
+		}
+		__syncthreads();  // the epilogue image goes over the stages
+	} else if (by_dma) {
 		// one barrier per K tile: it retires this tile's DMA (the fence in front of it drains vmcnt) and tells that every
 		// wave is done with the other stage, which the next tile's DMA then overwrites
 		dma_tile_k(smem, A, g.lda, m0, g.M, k_begin, wave, lane);
@@ -289,15 +405,19 @@ __device__ __forceinline__ void gemm_bf16_tile(BfArgs& a, char* smem, const int 
 	// acc[i][j][r]: m = wm + 16 i + (lane & 15), n = wn + 16 j + 4 (lane >> 4) + r
 	float* ct = reinterpret_cast<float*>(smem);
 	if constexpr (ALAYOUT == VITK_MN_MAJOR) {
-		if (do_colsum) {  // workgroup-uniform: the 16 row groups of a column combine through LDS (the stages are free now)
+		if (do_colsum) {  // workgroup-uniform: the 16 (2) row groups of a column combine through LDS (the stages are free now)
+			if (by_dma_mn) {
+				ct[tid] = csum1;
+			} else {
 #pragma unroll
-			for (int e = 0; e < 8; ++e) ct[(tid >> 4) * 128 + 8 * (tid & 15) + e] = csum[e];
+				for (int e = 0; e < 8; ++e) ct[(tid >> 4) * 128 + 8 * (tid & 15) + e] = csum[e];
+			}
 			__syncthreads();
 			if (tid < 128 && m0 + tid < g.M) {
 				float sum = 0.f;
-#pragma unroll
-				for (int r = 0; r < 16; ++r) sum += ct[r * 128 + tid];
-				if (a.cs_partials != nullptr) a.cs_partials[(int64_t)split * g.M + m0 + tid] = sum;
+				const int groups = by_dma_mn ? 2 : 16;
+				for (int r = 0; r < groups; ++r) sum += ct[r * 128 + tid];
+				if (a.cs_partials != nullptr) a.cs_partials[((int64_t)split * a.cs_turns + tn) * g.M + m0 + tid] = sum;
 				else if (a.splits > 1) atomicAdd(a.a_colsum + m0 + tid, sum);
 				else a.a_colsum[m0 + tid] += sum;  // the only workgroup that owns these rows
 			}
@@ -363,11 +483,19 @@ static_assert(sizeof(BfGroupArgs) <= 4096, "kernel argument block");
 
 __global__ __launch_bounds__(256, 2) void gemm_bf16_group_kernel(BfGroupArgs ga) {
 	extern __shared__ __attribute__((aligned(16))) char smem[];
+	// consecutive workgroup ids go to the 8 XCDs in turn: XCD x takes the x-th eighth of the list (problem, K slice, tile),
+	// so that the tiles of one K slice -- which share its operand rows -- run side by side behind one L2
+	const int total = ga.first[ga.n];
+	int v = blockIdx.x;
+	{
+		const int q = total >> 3, r = total & 7, xcd = v & 7, idx = v >> 3;
+		v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+	}
 	int gi = 0;
-	while (gi + 1 < ga.n && (int)blockIdx.x >= ga.first[gi + 1]) ++gi;
+	while (gi + 1 < ga.n && v >= ga.first[gi + 1]) ++gi;
 	BfArgs a = ga.p[gi];
-	const int local = (int)blockIdx.x - ga.first[gi], nwg = a.tiles_m * a.tiles_n;
-	gemm_bf16_tile<VITK_MN_MAJOR, VITK_MN_MAJOR, false, float>(a, smem, local % nwg, local / nwg);
+	const int local = v - ga.first[gi], nwg = a.tiles_m * a.tiles_n;
+	gemm_bf16_tile<VITK_MN_MAJOR, VITK_MN_MAJOR, false, float, false>(a, smem, local % nwg, local / nwg);
 }
 
 // C (+)= sum over the K slices of the partial tiles (block row `ty` < ntile),
@@ -377,8 +505,9 @@ struct ReduceItem {
 	float* C;
 	int64_t M, N, ldc;
 	int tiles_n, ntile, splits, accumulate;
-	const float* cs_partials;
+	const float* cs_partials;  // [cs_slots][M]
 	float* a_colsum;
+	int cs_slots;
 };
 
 __device__ __forceinline__ void split_reduce128_rows(const ReduceItem& r, const int ty) {
@@ -386,10 +515,10 @@ __device__ __forceinline__ void split_reduce128_rows(const ReduceItem& r, const 
 		if (r.cs_partials == nullptr) return;
 		for (int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x; m < r.M; m += (int64_t)gridDim.x * 256) {
 			float sum = 0.f;
-			for (int s0 = 0; s0 < r.splits; s0 += 16) {
+			for (int s0 = 0; s0 < r.cs_slots; s0 += 16) {
 				float t[16];
 #pragma unroll
-				for (int u = 0; u < 16; ++u) t[u] = s0 + u < r.splits ? r.cs_partials[(int64_t)(s0 + u) * r.M + m] : 0.f;
+				for (int u = 0; u < 16; ++u) t[u] = s0 + u < r.cs_slots ? r.cs_partials[(int64_t)(s0 + u) * r.M + m] : 0.f;
 #pragma unroll
 				for (int u = 0; u < 16; ++u) sum += t[u];
 			}
@@ -535,6 +664,9 @@ static bool fill128(const vitk_gemm_desc& d, BfArgs& a) {
 	if (fuse_colsum) a.a_colsum = d.a_colsum;
 	static const bool no_dma = getenv("VITK_NO_DMA128") != nullptr;  // A-B switch
 	a.dma = !no_dma && d.patch_grid == 0 && d.a_layout == VITK_K_MAJOR && d.b_layout == VITK_K_MAJOR && d.K % BK == 0 && d.M >= 1 && d.N >= 1;
+	static const bool no_dma_mn = getenv("VITK_NO_DMA128_MN") != nullptr;  // A-B switch
+	if (!no_dma_mn && d.patch_grid == 0 && d.a_layout == VITK_MN_MAJOR && d.b_layout == VITK_MN_MAJOR && d.K % BK == 0 && d.M >= 8 && d.N >= 8) a.dma = 2;
+	a.cs_turns = 1;
 	return fuse_colsum;
 }
 
@@ -559,10 +691,14 @@ int vitk_gemm_bf16_128(const vitk_gemm_desc& d, hipStream_t st, bool* colsum_don
 	a.splits = (int)vitk_cdiv(ktiles, kt_per);
 	if (a.splits > 1) {
 		const int64_t tile_bytes = (int64_t)a.splits * tiles * BM * BN * (int64_t)sizeof(float);
-		const int64_t need = tile_bytes + (fuse_colsum ? (int64_t)a.splits * d.M * (int64_t)sizeof(float) : 0);
+		const int turns = fuse_colsum && a.dma == 2 ? a.tiles_n : 1;
+		const int64_t need = tile_bytes + (fuse_colsum ? (int64_t)a.splits * turns * d.M * (int64_t)sizeof(float) : 0);
 		if (d.workspace != nullptr && d.workspace_bytes >= need && vitk_aligned(d.workspace, 16)) {
 			a.partials = reinterpret_cast<float*>(d.workspace);
-			if (fuse_colsum) a.cs_partials = a.partials + tile_bytes / (int64_t)sizeof(float);
+			if (fuse_colsum) {
+				a.cs_partials = a.partials + tile_bytes / (int64_t)sizeof(float);
+				a.cs_turns = turns;
+			}
 		}
 	}
 	if (a.splits > 1 && a.partials == nullptr && !d.accumulate) {
@@ -578,7 +714,7 @@ int vitk_gemm_bf16_128(const vitk_gemm_desc& d, hipStream_t st, bool* colsum_don
 	else if (d.a_layout == VITK_MN_MAJOR && d.b_layout == VITK_MN_MAJOR) rc = launch<VITK_MN_MAJOR, VITK_MN_MAJOR, false>(a, d.out_dtype, grid, st);
 	else rc = launch<VITK_MN_MAJOR, VITK_K_MAJOR, false>(a, d.out_dtype, grid, st);
 	if (rc == VITK_OK && a.partials != nullptr) {
-		const ReduceItem r{a.partials, reinterpret_cast<float*>(d.C), d.M, d.N, d.ldc, a.tiles_n, (int)tiles, a.splits, d.accumulate, a.cs_partials, d.a_colsum};
+		const ReduceItem r{a.partials, reinterpret_cast<float*>(d.C), d.M, d.N, d.ldc, a.tiles_n, (int)tiles, a.splits, d.accumulate, a.cs_partials, d.a_colsum, a.splits * a.cs_turns};
 		hipLaunchKernelGGL(split_reduce128_kernel, dim3(BM * BN / 256, (unsigned)tiles + 1), dim3(256), 0, st, r);
 		VITK_CHECK_LAUNCH();
 	}
@@ -645,9 +781,10 @@ int vitk_gemm_bf16_group128(const vitk_gemm_desc* const* ds, int n, hipStream_t 
 		used += (int64_t)a.splits * tiles[i] * BM * BN * (int64_t)sizeof(float);
 		if (fused[i]) {
 			a.cs_partials = reinterpret_cast<float*>(reinterpret_cast<char*>(d.workspace) + used);
-			used += vitk_cdiv((int64_t)a.splits * d.M * (int64_t)sizeof(float), 256) * 256;
+			a.cs_turns = a.dma == 2 ? a.tiles_n : 1;
+			used += vitk_cdiv((int64_t)a.splits * a.cs_turns * d.M * (int64_t)sizeof(float), 256) * 256;
 		}
-		rg.p[rg.n] = ReduceItem{a.partials, reinterpret_cast<float*>(d.C), d.M, d.N, d.ldc, a.tiles_n, (int)tiles[i], a.splits, d.accumulate, a.cs_partials, d.a_colsum};
+		rg.p[rg.n] = ReduceItem{a.partials, reinterpret_cast<float*>(d.C), d.M, d.N, d.ldc, a.tiles_n, (int)tiles[i], a.splits, d.accumulate, a.cs_partials, d.a_colsum, a.splits * a.cs_turns};
 		rg.first[rg.n] = row0;
 		row0 += (int)tiles[i] + 1;
 		++rg.n;
