@@ -74,6 +74,48 @@ def test_gemm_exact_integers(gpu, dtype):
 	assert torch.equal(c3.cpu().double(), ref.to(dtype).double())
 
 
+@pytest.mark.parametrize("M,N,K", [(4096, 384, 1536), (4096, 1152, 384), (1000, 264, 192), (520, 136, 448), (128, 128, 192), (2048, 64, 256), (72, 1024, 1024)])
+@pytest.mark.parametrize("a_mn,b_mn", [(False, False), (False, True), (True, True), (True, False)])
+def test_gemm_few_tiles_long_k(gpu, M, N, K, a_mn, b_mn):
+	"""The four-stage form of the 128x128 kernel (at most one workgroup per CU, K of three or more tiles: the GEMMs of a stage
+	with few tokens), every pair of operand layouts, ragged last tiles: small-integer operands, so the float32 result is
+	the exact sum and a wrong fragment, swizzle, stage or wait shows as a wrong integer; then the fused epilogues on it."""
+	import vit_amd._lib as L
+	from vit_amd import ops
+	g = torch.Generator().manual_seed(M + N + K)
+	a = torch.randint(-3, 4, (M, K), generator=g).to(torch.bfloat16)
+	b = torch.randint(-3, 4, (N, K), generator=g).to(torch.bfloat16)
+	ref = a.double() @ b.double().t()
+	A = (a.t().contiguous() if a_mn else a).to(gpu)
+	B = (b.t().contiguous() if b_mn else b).to(gpu)
+	for out_dtype in (torch.float32, torch.bfloat16):
+		c = torch.full((M, N), float("nan"), dtype=out_dtype, device=gpu)
+		ops.gemm(A, B, c, M, N, K, M if a_mn else K, N if b_mn else K, N, a_layout=L.MN_MAJOR if a_mn else L.K_MAJOR, b_layout=L.MN_MAJOR if b_mn else L.K_MAJOR,
+			workspace=False)
+		assert torch.equal(c.cpu().double(), ref.to(out_dtype).double())
+	if a_mn:
+		return
+	# bias + GELU with the pre-activation as second output; bias + LayerScale + residual; activation derivative
+	x, xr = rnd((M, K), torch.bfloat16, gpu, seed=1)
+	w, wr = rnd((N, K), torch.bfloat16, gpu, 0.1, seed=2)
+	W = w.t().contiguous() if b_mn else w
+	bias = torch.randn(N, generator=torch.Generator().manual_seed(3))
+	lay = dict(b_layout=L.MN_MAJOR if b_mn else L.K_MAJOR)
+	ldb = N if b_mn else K
+	pre_ref = xr @ wr.t() + bias.double()
+	y = torch.empty((M, N), dtype=torch.bfloat16, device=gpu)
+	pre = torch.empty_like(y)
+	ops.gemm(x, W, y, M, N, K, K, ldb, N, bias=bias.to(gpu), epilogue=L.EPI_ACT, act=L.ACT_GELU, out2=pre, ld_out2=N, **lay)
+	assert relerr(pre, pre_ref) < TOL[torch.bfloat16]
+	assert relerr(y, O.act_fwd(pre.cpu().double(), "gelu")) < TOL[torch.bfloat16]
+	res, rr = rnd((M, N), torch.bfloat16, gpu, seed=4)
+	gamma = torch.rand(N, generator=torch.Generator().manual_seed(5)) + 0.5
+	ops.gemm(x, W, y, M, N, K, K, ldb, N, bias=bias.to(gpu), epilogue=L.EPI_RESIDUAL, aux=res, ld_aux=N, gamma=gamma.to(gpu), **lay)
+	assert relerr(y, rr + gamma.double() * pre_ref) < TOL[torch.bfloat16]
+	ops.gemm(x, W, y, M, N, K, K, ldb, N, epilogue=L.EPI_ACTGRAD, act=L.ACT_GELU, aux=pre, ld_aux=N, **lay)
+	assert relerr(y, (xr @ wr.t()) * O.act_grad(pre.cpu().double(), "gelu")) < TOL[torch.bfloat16]
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("act", ["gelu", "silu", "relu", "relu6"])
 def test_gemm_epilogues(gpu, dtype, act):
@@ -351,7 +393,7 @@ def test_gemm_group_matches_separate_launches(gpu, name):
 	held = []
 	grouped = run(held)
 	assert len(held) == len(probs)
-	descs = (L.GemmDesc * len(held))(*[d for d, _ in held])
+	descs = (L.GemmDesc * len(held))(*[h[0] for h in held])
 	L.check(L.load().vitk_gemm_group(descs, len(held), L.stream()))
 	if name in ("vit_tiny_block", "cvt_stage1_block", "cvt_stage3_block", "mixed_lengths", "twelve"):
 		assert L.load().vitk_gemm_last_kernel().decode() == "gemm_bf16_group_kernel"

@@ -28,6 +28,8 @@ constexpr int TILE_BYTES = 128 * 64 * 2;  // 16 KiB, both layouts
 constexpr int STAGE_BYTES = 2 * TILE_BYTES;
 constexpr int CT_LD = 132;                                   // floats per row of the epilogue image (128 + 4 pad)
 constexpr int LDS_BYTES = 128 * CT_LD * 4;                   // 67,584 B >= the two operand stages (65,536 B)
+constexpr int DEEP_STAGES = 4;                               // the deep-pipeline form: four stages, one workgroup per CU
+constexpr int DEEP_LDS_BYTES = DEEP_STAGES * STAGE_BYTES;    // 131,072 B
 
 __device__ __forceinline__ int swz_k(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
 __device__ __forceinline__ int swz_mn(int krow, int chunk) {
@@ -38,6 +40,7 @@ __device__ __forceinline__ int swz_mn(int krow, int chunk) {
 struct Frag {
 	bf16x8 v;
 };
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 // fragment read: 16 rows (or cols) starting at `base`, k-step s (32 wide) of the staged 64-wide K tile
 template <int LAYOUT>
@@ -121,7 +124,7 @@ struct BfArgs {
 	GemmDev g;
 	int tiles_m, tiles_n, splits, k_per_split;  // k_per_split is a multiple of BK
 	int vec4;                                    // epilogue may use 4-wide accesses
-	int dma;                                     // K % 64 == 0: operand tiles by LDS-DMA; 1: K-major x K-major, 2: MN-major x MN-major
+	int dma;                                     // K % 64 == 0: operand tiles by LDS-DMA; 1: K-major x K-major, 2: MN-major x MN-major, 3: any layouts, four stages
 	int cs_turns;                                // workgroups (tile columns) that take turns, K tile by K tile, at the column sums of their A tile
 	float* partials;                             // K split through scratch: [split][tile][128 x 128] partial tiles (else float atomics into C)
 	float* cs_partials;                          // [split][M] partial column sums of A (with partials and a_colsum)
@@ -272,7 +275,100 @@ __device__ __forceinline__ void gemm_bf16_tile(BfArgs& a, char* smem, const int 
 	if constexpr (ALAYOUT == VITK_K_MAJOR && BLAYOUT == VITK_K_MAJOR && !PATCH) by_dma = a.dma == 1;
 	if constexpr (ALAYOUT == VITK_MN_MAJOR && BLAYOUT == VITK_MN_MAJOR && !PATCH) by_dma_mn = a.dma == 2;
 	float csum1 = 0.f;  // by_dma_mn: column tid & 127 of the A tile over k-rows 32 (tid >> 7) .. + 31, of the K tiles that are this workgroup's turn
-	if (by_dma_mn) {
+	bool by_deep = false;
+	if constexpr (!PATCH) by_deep = a.dma == 3;
+	if (by_deep) {
+		// Few workgroups (at most one per CU) over a K of several tiles: with two stages a K tile costs a whole memory round
+		// trip, because the only request in flight is the next tile's.  Four stages, three tiles requested ahead, counted
+		// waits: tile t is waited for with the requests of up to two newer tiles (8 per wave and tile) still in flight.
+		// Either layout per operand; every LDS read is inline asm (the compiler would wait vmcnt(0) in front of reads it
+		// can see).  The barrier of step t also tells that every wave is done with stage (t - 1) % 4, which the request
+		// issued right behind it refills.
+		constexpr int ST = DEEP_STAGES;
+		const uint32_t lds0 = lds_addr(smem);
+		const int fg = lane >> 4, fq = (lane >> 2) & 3, fp = lane & 3;
+		auto lane_k = [&](int base, int s) { return (uint32_t)swz_k(base + (lane & 15), 4 * s + fg); };  // + 2048 per fragment
+		auto lane_mn = [&](int base) { return (uint32_t)(swz_mn(8 * fg + fq, (base >> 3) + (fp >> 1)) + ((fp & 1) << 3)); };  // ^ (fragment << 5)
+		const uint32_t a_k0 = lane_k(wm, 0), a_k1 = lane_k(wm, 1), b_k0 = lane_k(wn, 0), b_k1 = lane_k(wn, 1);
+		const uint32_t a_mn = lane_mn(wm), b_mn = lane_mn(wn);
+		auto issue = [&](int t) {  // K tile t of this slice into stage t % ST
+			char* da = smem + (t % ST) * STAGE_BYTES;
+			const int k0 = k_begin + t * BK;
+			if constexpr (ALAYOUT == VITK_K_MAJOR) dma_tile_k(da, A, g.lda, m0, g.M, k0, wave, lane);
+			else dma_tile_mn(da, A, g.lda, m0, g.M, k0, wave, lane);
+			if constexpr (BLAYOUT == VITK_K_MAJOR) dma_tile_k(da + TILE_BYTES, B, g.ldb, n0, g.N, k0, wave, lane);
+			else dma_tile_mn(da + TILE_BYTES, B, g.ldb, n0, g.N, k0, wave, lane);
+		};
+		for (int t = 0; t < ST - 1 && t < nt; ++t) issue(t);
+		for (int t = 0; t < nt; ++t) {
+			const int newer = min(nt - 1, t + ST - 2) - t;  // tiles requested behind tile t
+			if (newer >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+			else if (newer == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+			else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+			__builtin_amdgcn_s_barrier();
+			if (t + ST - 1 < nt) issue(t + ST - 1);
+			const uint32_t sa = lds0 + (t % ST) * STAGE_BYTES, sb = sa + TILE_BYTES;
+			u32x4 ka[4][2], kb[4][2];            // K-major fragments [fragment][k half]
+			s16x4 ta[4][2][2], tb[4][2][2];      // MN-major fragments [fragment][k half][read]
+			auto read_half = [&](int s) {
+				if constexpr (BLAYOUT == VITK_K_MAJOR) {
+#pragma unroll
+					for (int j = 0; j < 4; ++j) asm volatile("ds_read_b128 %0, %1" : "=v"(kb[j][s]) : "v"(sb + (s ? b_k1 : b_k0) + 2048 * j));
+				} else {
+#pragma unroll
+					for (int j = 0; j < 4; ++j) {
+						asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(tb[j][s][0]) : "v"(sb + (b_mn ^ (j << 5)) + 8192 * s));
+						asm volatile("ds_read_b64_tr_b16 %0, %1 offset:1024" : "=v"(tb[j][s][1]) : "v"(sb + (b_mn ^ (j << 5)) + 8192 * s));
+					}
+				}
+				if constexpr (ALAYOUT == VITK_K_MAJOR) {
+#pragma unroll
+					for (int i = 0; i < 4; ++i) asm volatile("ds_read_b128 %0, %1" : "=v"(ka[i][s]) : "v"(sa + (s ? a_k1 : a_k0) + 2048 * i));
+				} else {
+#pragma unroll
+					for (int i = 0; i < 4; ++i) {
+						asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(ta[i][s][0]) : "v"(sa + (a_mn ^ (i << 5)) + 8192 * s));
+						asm volatile("ds_read_b64_tr_b16 %0, %1 offset:1024" : "=v"(ta[i][s][1]) : "v"(sa + (a_mn ^ (i << 5)) + 8192 * s));
+					}
+				}
+			};
+			auto landed = [&](int s) {  // ties the registers of k half s to the wait in front of this statement
+				if constexpr (BLAYOUT == VITK_K_MAJOR) asm volatile("" : "+v"(kb[0][s]), "+v"(kb[1][s]), "+v"(kb[2][s]), "+v"(kb[3][s])::"memory");
+				else asm volatile("" : "+v"(tb[0][s][0]), "+v"(tb[0][s][1]), "+v"(tb[1][s][0]), "+v"(tb[1][s][1]), "+v"(tb[2][s][0]), "+v"(tb[2][s][1]), "+v"(tb[3][s][0]), "+v"(tb[3][s][1])::"memory");
+				if constexpr (ALAYOUT == VITK_K_MAJOR) asm volatile("" : "+v"(ka[0][s]), "+v"(ka[1][s]), "+v"(ka[2][s]), "+v"(ka[3][s])::"memory");
+				else asm volatile("" : "+v"(ta[0][s][0]), "+v"(ta[0][s][1]), "+v"(ta[1][s][0]), "+v"(ta[1][s][1]), "+v"(ta[2][s][0]), "+v"(ta[2][s][1]), "+v"(ta[3][s][0]), "+v"(ta[3][s][1])::"memory");
+			};
+			auto mma_half = [&](int s) {
+#pragma unroll
+				for (int i = 0; i < 4; ++i)
+#pragma unroll
+					for (int j = 0; j < 4; ++j) {
+						bf16x8 xf, wf;
+						if constexpr (ALAYOUT == VITK_K_MAJOR) xf = __builtin_bit_cast(bf16x8, ka[i][s]);
+						else xf = join8(ta[i][s][0], ta[i][s][1]);
+						if constexpr (BLAYOUT == VITK_K_MAJOR) wf = __builtin_bit_cast(bf16x8, kb[j][s]);
+						else wf = join8(tb[j][s][0], tb[j][s][1]);
+						acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf, acc[i][j], 0, 0, 0);
+					}
+			};
+			// LDS reads return in order: the second half's reads (8 ... 16 of them) may still be in flight while the first
+			// half's MFMAs run
+			constexpr int HALF_READS = (ALAYOUT == VITK_K_MAJOR ? 4 : 8) + (BLAYOUT == VITK_K_MAJOR ? 4 : 8);
+			read_half(0);
+			read_half(1);
+			if constexpr (HALF_READS == 8) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+			else if constexpr (HALF_READS == 12) asm volatile("s_waitcnt lgkmcnt(12)" ::: "memory");
+			else asm volatile("s_waitcnt lgkmcnt(15)" ::: "memory");
+			landed(0);
+			mma_half(0);
+			__builtin_amdgcn_sched_barrier(0);
+			asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+			landed(1);
+			mma_half(1);
+		}
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		__syncthreads();  // the epilogue image goes over the stages
+	} else if (by_dma_mn) {
 		// as below (one barrier per K tile), with both MN-major tiles staged by LDS-DMA and every LDS read issued as inline asm
 		const uint32_t lds0 = lds_addr(smem);
 		const int fg = lane >> 4, fq = (lane >> 2) & 3, fp = lane & 3;
@@ -582,12 +678,12 @@ __global__ __launch_bounds__(256) void split_reduce128_group_kernel(ReduceGroup 
 
 template <int AL, int BL, bool PATCH>
 int launch(const BfArgs& a, int out_dtype, dim3 grid, hipStream_t st) {
-	const size_t lds = LDS_BYTES;
+	const size_t lds = a.dma == 3 ? DEEP_LDS_BYTES : LDS_BYTES;
 	static bool attr_set[2] = {false, false};  // per template instantiation (function-local static)
 	const int oi = out_dtype == VITK_BF16 ? 0 : 1;
 	if (!attr_set[oi]) {
-		hipError_t e = oi == 0 ? hipFuncSetAttribute((const void*)gemm_bf16_kernel<AL, BL, PATCH, bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
-							   : hipFuncSetAttribute((const void*)gemm_bf16_kernel<AL, BL, PATCH, float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+		hipError_t e = oi == 0 ? hipFuncSetAttribute((const void*)gemm_bf16_kernel<AL, BL, PATCH, bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, DEEP_LDS_BYTES)
+							   : hipFuncSetAttribute((const void*)gemm_bf16_kernel<AL, BL, PATCH, float>, hipFuncAttributeMaxDynamicSharedMemorySize, DEEP_LDS_BYTES);
 		if (e != hipSuccess) return VITK_ERR_HIP - (int)e;
 		attr_set[oi] = true;
 	}
@@ -632,7 +728,9 @@ int vitk_gemm_bf16(const vitk_gemm_desc& d, hipStream_t st, bool* colsum_done) {
 	const int64_t t256n = vitk_cdiv(d.M, 256) * vitk_cdiv(d.N, 256);
 	const bool starved = small_rule && d.out_dtype == VITK_BF16 && t256n < 128;  // (thresholds 64 ... 256 measured the same on the CvT step: 7.9 -> 6.6 ms)
 	static const bool p8 = getenv("VITK_NO_P8") == nullptr;  // A-B switch
-	if (p8 && big_tiles && d.a_colsum == nullptr && vitk_gemm_bf16_p8_ok(d) && d.M * d.N >= 32ll * 256 * 256) {
+	// (at least 64 tiles' worth of output: measured on the 32 x 32 models, 32 / 64 / 100 tiles as the bound: CvT 4.09 / 4.04 / 4.04 ms,
+	// ViT-Tiny 4.91 / 4.91 / 5.64 ms per step)
+	if (p8 && big_tiles && d.a_colsum == nullptr && vitk_gemm_bf16_p8_ok(d) && d.M * d.N >= 64ll * 256 * 256) {
 		// (Cutting a launch whose last round is mostly empty -- N = 768: 591 tiles = 2.31 rounds -- into whole rounds here plus
 		// the remaining rows on the 128x256-tile kernel was measured on the ViT-B/16 step: 0.6 ms slower, so it is not done.)
 		return vitk_gemm_bf16_p8(d, st);
@@ -705,6 +803,11 @@ int vitk_gemm_bf16_128(const vitk_gemm_desc& d, hipStream_t st, bool* colsum_don
 		hipError_t e = vitk_zero_f32_2d(reinterpret_cast<float*>(d.C), d.M, d.N, d.ldc, st);
 		if (e != hipSuccess) return VITK_ERR_HIP - (int)e;
 	}
+	// at most one workgroup per CU and a K of several tiles per workgroup: the four-stage form (see the kernel)
+	static const bool no_deep = getenv("VITK_NO_DEEP128") != nullptr;  // A-B switch
+	if (!no_deep && d.patch_grid == 0 && d.K % BK == 0 && a.a_colsum == nullptr && d.a_colsum == nullptr && tiles * a.splits <= 256 && kt_per >= 3 &&
+		(d.a_layout == VITK_K_MAJOR || d.M >= 8) && (d.b_layout == VITK_K_MAJOR || d.N >= 8))
+		a.dma = 3;
 	dim3 grid((unsigned)tiles, (unsigned)a.splits);
 	const bool patch = d.patch_grid > 0;
 	int rc;

@@ -587,7 +587,7 @@ def wgrad_group():
 	if len(held) == 1:
 		L.check(L.load().vitk_gemm(held[0][0], L.stream()))
 	elif held:
-		descs = (L.GemmDesc * len(held))(*[d for d, _ in held])
+		descs = (L.GemmDesc * len(held))(*[h[0] for h in held])
 		L.check(L.load().vitk_gemm_group(descs, len(held), L.stream()))
 		GROUP_CALLS += 1
 	reports = list(_wgrad_held_done)
@@ -1639,7 +1639,7 @@ def _conv_attn_backward(dy2, x2, qkv, kv1, o, lse, wqkv, ckv, wo, geom, Skv, sk,
 	[dbq, dbk, dbv], dckv, dwo, dbo) with the parameter gradients as autograd wants them (None where a sink took them)."""
 	Bn, H, W, n_head, ks, stride, pad = geom
 	C = x2.shape[1]
-	dwo, dbo = linear_wgrad(dy2, o, bias_grad=True, dw_out=sk.buf("wo"), db_out=sk.buf("bo"))
+	dwo, dbo = linear_wgrad(dy2, o, bias_grad=True, dw_out=sk.buf("wo"), db_out=sk.buf("bo"), overlap=True)
 	do = linear_dgrad(dy2, wo)
 	dqkv = torch.empty_like(qkv)
 	dkv1 = torch.empty_like(kv1)
@@ -1650,7 +1650,7 @@ def _conv_attn_backward(dy2, x2, qkv, kv1, o, lse, wqkv, ckv, wo, geom, Skv, sk,
 	w_sink = _joint([sk.buf("wq"), sk.buf("wk"), sk.buf("wv")])
 	b_sink = _joint([sk.buf("bq"), sk.buf("bk"), sk.buf("bv")])
 	by_hand = (w_sink is None and any(sk.buf(n) is not None for n in ("wq", "wk", "wv"))) or (b_sink is None and any(sk.buf(n) is not None for n in ("bq", "bk", "bv")))
-	dw3, db3 = linear_wgrad(dqkv, x2, bias_grad=True, dw_out=w_sink, db_out=b_sink, group=not by_hand)
+	dw3, db3 = linear_wgrad(dqkv, x2, bias_grad=True, dw_out=w_sink, db_out=b_sink, group=not by_hand, overlap=not by_hand)  # (dqkv is complete: the convolution's input gradient went into it above)
 
 	def hand_out(names, joint_sink, g3):
 		out = []
