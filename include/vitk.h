@@ -388,6 +388,10 @@ int vitk_dwconv_fwd_ld(const void* x, int64_t ldx, const void* w, void* y, int64
 	int64_t ks, int64_t stride, int64_t pad, int dtype, void* stream);
 int vitk_dwconv_bwd_ld(const void* dy, const void* x, int64_t ldx, const void* w, void* dx, int64_t lddx, float* dw, int64_t B,
 	int64_t H, int64_t W, int64_t C, int64_t ks, int64_t stride, int64_t pad, int dtype, void* stream);
+/* ... and with accumulate_dw != 0 the weight gradient is ADDED into dw (a gradient sink that already holds this step's other
+ * contributions; the caller owns its zeroing) instead of overwriting it: saves the fill and the add kernel per ConvAttention. */
+int vitk_dwconv_bwd_acc(const void* dy, const void* x, int64_t ldx, const void* w, void* dx, int64_t lddx, float* dw, int accumulate_dw,
+	int64_t B, int64_t H, int64_t W, int64_t C, int64_t ks, int64_t stride, int64_t pad, int dtype, void* stream);
 /* im2col for the overlapping conv token embedding (layers/embeddings.py:21): x NCHW -> cols [B*Ho*Wo, C*ks*ks]
  * (the convolution itself is vitk_gemm on cols) and col2im (scatter-add) for its input gradient.
  * With tokens_in != 0 the input is token-major [B, H*W, C] (the layout CvT blocks produce), so the

@@ -100,6 +100,7 @@ SIGNATURES = {
 	"vitk_dwconv_bwd": [P, P, P, P, P, I64, I64, I64, I64, I64, I64, I64, I, P],
 	"vitk_dwconv_fwd_ld": [P, I64, P, P, I64, I64, I64, I64, I64, I64, I64, I, P],
 	"vitk_dwconv_bwd_ld": [P, P, I64, P, P, I64, P, I64, I64, I64, I64, I64, I64, I64, I, P],
+	"vitk_dwconv_bwd_acc": [P, P, I64, P, P, I64, P, I, I64, I64, I64, I64, I64, I64, I64, I, P],
 	"vitk_im2col": [P, P, I64, I64, I64, I64, I64, I64, I64, I64, I, I, P],
 	"vitk_col2im": [P, P, I64, I64, I64, I64, I64, I64, I64, I64, I, I, P],
 	"vitk_pad_cols": [P, P, I64, I64, I64, I64, I, I, P],

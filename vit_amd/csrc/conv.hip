@@ -642,14 +642,16 @@ extern "C" int vitk_dwconv_fwd(const void* x, const void* w, void* y, int64_t B,
 	return vitk_dwconv_fwd_ld(x, C, w, y, B, H, W, C, ks, stride, pad, dtype, stream);
 }
 
-extern "C" int vitk_dwconv_bwd_ld(const void* dy, const void* x, int64_t ldx, const void* w, void* dx, int64_t lddx, float* dw, int64_t B, int64_t H, int64_t W,
-	int64_t C, int64_t ks, int64_t stride, int64_t pad, int dtype, void* stream) {
+extern "C" int vitk_dwconv_bwd_acc(const void* dy, const void* x, int64_t ldx, const void* w, void* dx, int64_t lddx, float* dw, int accumulate_dw, int64_t B,
+	int64_t H, int64_t W, int64_t C, int64_t ks, int64_t stride, int64_t pad, int dtype, void* stream) {
 	VITK_REQUIRE(dy && x && w && dx && dw, VITK_ERR_NULL);
 	int64_t Ho, Wo;
 	VITK_REQUIRE(B > 0 && C > 0 && ldx >= C && lddx >= C && conv_geom(H, W, ks, stride, pad, &Ho, &Wo) && ks <= 5, VITK_ERR_SHAPE);
 	hipStream_t st = (hipStream_t)stream;
-	hipError_t e = vitk_zero_f32(dw, C * ks * ks, st);
-	if (e != hipSuccess) return VITK_ERR_HIP - (int)e;
+	if (!accumulate_dw) {  // (the kernels add their partial sums into dw)
+		hipError_t e = vitk_zero_f32(dw, C * ks * ks, st);
+		if (e != hipSuccess) return VITK_ERR_HIP - (int)e;
+	}
 	DISPATCH_T(dtype, {
 		constexpr int V = VecOf<T>::N;
 		if (ks == 3 && C % V == 0 && ldx % V == 0 && lddx % V == 0 && vitk_aligned(x, 16) && vitk_aligned(dy, 16) && vitk_aligned(dx, 16)) {
@@ -673,6 +675,11 @@ extern "C" int vitk_dwconv_bwd_ld(const void* dy, const void* x, int64_t ldx, co
 		VITK_CHECK_LAUNCH();
 		return VITK_OK;
 	});
+}
+
+extern "C" int vitk_dwconv_bwd_ld(const void* dy, const void* x, int64_t ldx, const void* w, void* dx, int64_t lddx, float* dw, int64_t B, int64_t H, int64_t W,
+	int64_t C, int64_t ks, int64_t stride, int64_t pad, int dtype, void* stream) {
+	return vitk_dwconv_bwd_acc(dy, x, ldx, w, dx, lddx, dw, 0, B, H, W, C, ks, stride, pad, dtype, stream);
 }
 
 extern "C" int vitk_dwconv_bwd(const void* dy, const void* x, const void* w, void* dx, float* dw, int64_t B, int64_t H, int64_t W, int64_t C, int64_t ks,

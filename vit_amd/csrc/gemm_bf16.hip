@@ -198,7 +198,9 @@ __device__ __forceinline__ void store_frag(const BfArgs& a, int64_t m, int64_t n
 }
 
 // One 128 x 128 output tile over one K slice: workgroup `wg_in` of the problem's tiles_m * tiles_n, K slice `split`.
-template <int ALAYOUT, int BLAYOUT, bool PATCH, typename TOUT, bool XCD_REMAP = true>
+// PROD: the four-stage form in a 512-thread workgroup whose waves 4 .. 7 only issue the LDS-DMA requests (and leave before
+// the epilogue), so that waves 0 .. 3 never pay for them.
+template <int ALAYOUT, int BLAYOUT, bool PATCH, typename TOUT, bool XCD_REMAP = true, bool PROD = false>
 __device__ __forceinline__ void gemm_bf16_tile(BfArgs& a, char* smem, const int wg_in, const int split) {
 	gemm_dev_enter(a.g);
 	const GemmDev& g = a.g;
@@ -275,16 +277,19 @@ __device__ __forceinline__ void gemm_bf16_tile(BfArgs& a, char* smem, const int 
 	if constexpr (ALAYOUT == VITK_K_MAJOR && BLAYOUT == VITK_K_MAJOR && !PATCH) by_dma = a.dma == 1;
 	if constexpr (ALAYOUT == VITK_MN_MAJOR && BLAYOUT == VITK_MN_MAJOR && !PATCH) by_dma_mn = a.dma == 2;
 	float csum1 = 0.f;  // by_dma_mn: column tid & 127 of the A tile over k-rows 32 (tid >> 7) .. + 31, of the K tiles that are this workgroup's turn
-	bool by_deep = false;
-	if constexpr (!PATCH) by_deep = a.dma == 3;
+	const bool by_deep = PROD ? true : (!PATCH && a.dma == 3);
 	if (by_deep) {
 		// Few workgroups (at most one per CU) over a K of several tiles: with two stages a K tile costs a whole memory round
 		// trip, because the only request in flight is the next tile's.  Four stages, three tiles requested ahead, counted
 		// waits: tile t is waited for with the requests of up to two newer tiles (8 per wave and tile) still in flight.
 		// Either layout per operand; every LDS read is inline asm (the compiler would wait vmcnt(0) in front of reads it
 		// can see).  The barrier of step t also tells that every wave is done with stage (t - 1) % 4, which the request
-		// issued right behind it refills.
+		// issued right behind it refills.  PROD: a request costs the wave that issues it about 100 cycles, 800 per K tile --
+		// as much as the tile's fragment reads and MFMAs -- so four more waves do nothing else: they wait for their own
+		// requests, meet the others at the barrier (which publishes the tile) and request three tiles ahead.
 		constexpr int ST = DEEP_STAGES;
+		const bool requests = !PROD || wave >= 4, computes = !PROD || wave < 4;  // wave-uniform
+		const int pw = wave & 3;
 		const uint32_t lds0 = lds_addr(smem);
 		const int fg = lane >> 4, fq = (lane >> 2) & 3, fp = lane & 3;
 		auto lane_k = [&](int base, int s) { return (uint32_t)swz_k(base + (lane & 15), 4 * s + fg); };  // + 2048 per fragment
@@ -294,19 +299,23 @@ __device__ __forceinline__ void gemm_bf16_tile(BfArgs& a, char* smem, const int 
 		auto issue = [&](int t) {  // K tile t of this slice into stage t % ST
 			char* da = smem + (t % ST) * STAGE_BYTES;
 			const int k0 = k_begin + t * BK;
-			if constexpr (ALAYOUT == VITK_K_MAJOR) dma_tile_k(da, A, g.lda, m0, g.M, k0, wave, lane);
-			else dma_tile_mn(da, A, g.lda, m0, g.M, k0, wave, lane);
-			if constexpr (BLAYOUT == VITK_K_MAJOR) dma_tile_k(da + TILE_BYTES, B, g.ldb, n0, g.N, k0, wave, lane);
-			else dma_tile_mn(da + TILE_BYTES, B, g.ldb, n0, g.N, k0, wave, lane);
+			if constexpr (ALAYOUT == VITK_K_MAJOR) dma_tile_k(da, A, g.lda, m0, g.M, k0, pw, lane);
+			else dma_tile_mn(da, A, g.lda, m0, g.M, k0, pw, lane);
+			if constexpr (BLAYOUT == VITK_K_MAJOR) dma_tile_k(da + TILE_BYTES, B, g.ldb, n0, g.N, k0, pw, lane);
+			else dma_tile_mn(da + TILE_BYTES, B, g.ldb, n0, g.N, k0, pw, lane);
 		};
-		for (int t = 0; t < ST - 1 && t < nt; ++t) issue(t);
+		if (requests)
+			for (int t = 0; t < ST - 1 && t < nt; ++t) issue(t);
 		for (int t = 0; t < nt; ++t) {
-			const int newer = min(nt - 1, t + ST - 2) - t;  // tiles requested behind tile t
-			if (newer >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-			else if (newer == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-			else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+			if (requests) {
+				const int newer = min(nt - 1, t + ST - 2) - t;  // tiles requested behind tile t
+				if (newer >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+				else if (newer == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+				else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+			}
 			__builtin_amdgcn_s_barrier();
-			if (t + ST - 1 < nt) issue(t + ST - 1);
+			if (requests && t + ST - 1 < nt) issue(t + ST - 1);
+			if (!computes) continue;
 			const uint32_t sa = lds0 + (t % ST) * STAGE_BYTES, sb = sa + TILE_BYTES;
 			u32x4 ka[4][2], kb[4][2];            // K-major fragments [fragment][k half]
 			s16x4 ta[4][2][2], tb[4][2][2];      // MN-major fragments [fragment][k half][read]
@@ -367,6 +376,7 @@ __device__ __forceinline__ void gemm_bf16_tile(BfArgs& a, char* smem, const int 
 			mma_half(1);
 		}
 		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		if (PROD && !computes) return;  // (a barrier waits for the waves that are still there)
 		__syncthreads();  // the epilogue image goes over the stages
 	} else if (by_dma_mn) {
 		// as below (one barrier per K tile), with both MN-major tiles staged by LDS-DMA and every LDS read issued as inline asm
@@ -565,6 +575,12 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(BfArgs a) {
 	gemm_bf16_tile<ALAYOUT, BLAYOUT, PATCH, TOUT>(a, smem, blockIdx.x, blockIdx.y);
 }
 
+template <int ALAYOUT, int BLAYOUT, typename TOUT>
+__global__ __launch_bounds__(512, 1) void gemm_bf16_deep_kernel(BfArgs a) {
+	extern __shared__ __attribute__((aligned(16))) char smem[];
+	gemm_bf16_tile<ALAYOUT, BLAYOUT, false, TOUT, true, true>(a, smem, blockIdx.x, blockIdx.y);
+}
+
 // Several independent weight-gradient products (MN-major x MN-major, float32 result, K split through scratch) in one
 // launch: a block of a small model has four of them, each too small to fill the chip without cutting K so finely that
 // the partial tiles cost as much as the product.  Workgroups [first[i], first[i + 1]) belong to problem i, K slice by
@@ -676,8 +692,25 @@ __global__ __launch_bounds__(256) void split_reduce128_group_kernel(ReduceGroup 
 	split_reduce128_rows(r, (int)blockIdx.y - rg.first[gi]);
 }
 
+template <int AL, int BL, typename TOUT>
+int launch_deep(const BfArgs& a, dim3 grid, hipStream_t st) {
+	static bool attr_set = false;
+	if (!attr_set) {
+		hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_deep_kernel<AL, BL, TOUT>, hipFuncAttributeMaxDynamicSharedMemorySize, DEEP_LDS_BYTES);
+		if (e != hipSuccess) return VITK_ERR_HIP - (int)e;
+		attr_set = true;
+	}
+	hipLaunchKernelGGL((gemm_bf16_deep_kernel<AL, BL, TOUT>), grid, dim3(512), DEEP_LDS_BYTES, st, a);
+	VITK_CHECK_LAUNCH();
+	return VITK_OK;
+}
+
 template <int AL, int BL, bool PATCH>
 int launch(const BfArgs& a, int out_dtype, dim3 grid, hipStream_t st) {
+	static const bool no_prod = getenv("VITK_NO_DEEP128_PRODUCERS") != nullptr;  // A-B switch
+	if constexpr (!PATCH) {
+		if (a.dma == 3 && !no_prod) return out_dtype == VITK_BF16 ? launch_deep<AL, BL, bf16_t>(a, grid, st) : launch_deep<AL, BL, float>(a, grid, st);
+	}
 	const size_t lds = a.dma == 3 ? DEEP_LDS_BYTES : LDS_BYTES;
 	static bool attr_set[2] = {false, false};  // per template instantiation (function-local static)
 	const int oi = out_dtype == VITK_BF16 ? 0 : 1;

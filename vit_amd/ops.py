@@ -1588,16 +1588,22 @@ def dwconv_fwd(x, w, Bn, H, W, C, ks, stride, pad):
 	return y, Ho * Wo
 
 
-def dwconv_bwd(dy, x, w, Bn, H, W, C, ks, stride, pad, dx=None):
-	"""(dx, dw) of dwconv_fwd; x and the optional output dx [Bn * H * W, C] may be column slices of wider buffers."""
+def dwconv_bwd(dy, x, w, Bn, H, W, C, ks, stride, pad, dx=None, dw_out=None):
+	"""(dx, dw) of dwconv_fwd; x and the optional output dx [Bn * H * W, C] may be column slices of wider buffers.  dw_out:
+	a float32 [C, 1, ks, ks] buffer the weight gradient is ADDED into (a gradient sink), returned in place of a fresh tensor."""
 	assert x.stride(1) == 1 and dy.is_contiguous()
 	if dx is None:
 		dx = torch.empty((Bn * H * W, C), dtype=x.dtype, device=x.device)
 	assert dx.stride(1) == 1 and dx.shape == (Bn * H * W, C)
-	dw = torch.empty((C, 1, ks, ks), dtype=torch.float32, device=x.device)
-	L.check(L.load().vitk_dwconv_bwd_ld(L.ptr(dy), L.ptr(x), x.stride(0), L.ptr(w), L.ptr(dx), dx.stride(0), L.ptr(dw), Bn, H, W, C, ks, stride, pad,
-		L.dtype_code(x.dtype), L.stream()))
+	if dw_out is not None:
+		assert dw_out.dtype == torch.float32 and dw_out.is_contiguous() and dw_out.numel() == C * ks * ks
+	dw = dw_out if dw_out is not None else torch.empty((C, 1, ks, ks), dtype=torch.float32, device=x.device)
+	L.check(L.load().vitk_dwconv_bwd_acc(L.ptr(dy), L.ptr(x), x.stride(0), L.ptr(w), L.ptr(dx), dx.stride(0), L.ptr(dw), int(dw_out is not None), Bn, H, W, C, ks,
+		stride, pad, L.dtype_code(x.dtype), L.stream()))
 	return dx, dw
+
+
+DWCONV_SINK = os.environ.get("VITK_DWCONV_SINK", "1") != "0"  # A-B switch: depthwise-convolution weight gradients straight into their sinks
 
 
 def _joint(ts):
@@ -1635,8 +1641,8 @@ def _conv_attn_forward(x2, wqkv, bqkv, ckv, wo, bo, geom, residual=None, drop=(0
 
 
 def _conv_attn_backward(dy2, x2, qkv, kv1, o, lse, wqkv, ckv, wo, geom, Skv, sk, need_dx=True, drop=(0.0, 0)):
-	"""Backward of _conv_attn_forward.  sk: a _Sinks over the names wq bq wk bk wv bv wo bo.  Returns (dx, [dwq, dwk, dwv],
-	[dbq, dbk, dbv], dckv, dwo, dbo) with the parameter gradients as autograd wants them (None where a sink took them)."""
+	"""Backward of _conv_attn_forward.  sk: a _Sinks over the names wq bq wk bk wv bv ck cv wo bo.  Returns (dx, [dwq, dwk, dwv],
+	[dbq, dbk, dbv], [dck, dcv], dwo, dbo) with the parameter gradients as autograd wants them (None where a sink took them)."""
 	Bn, H, W, n_head, ks, stride, pad = geom
 	C = x2.shape[1]
 	dwo, dbo = linear_wgrad(dy2, o, bias_grad=True, dw_out=sk.buf("wo"), db_out=sk.buf("bo"), overlap=True)
@@ -1644,7 +1650,8 @@ def _conv_attn_backward(dy2, x2, qkv, kv1, o, lse, wqkv, ckv, wo, geom, Skv, sk,
 	dqkv = torch.empty_like(qkv)
 	dkv1 = torch.empty_like(kv1)
 	attention_bwd(do, qkv[:, :C], kv1[:, :C], kv1[:, C:], o, lse, dqkv[:, :C], dkv1[:, :C], dkv1[:, C:], Bn, n_head, H * W, Skv, C // n_head, drop=drop)
-	_, dckv = dwconv_bwd(dkv1, qkv[:, C:], ckv, Bn, H, W, 2 * C, ks, stride, pad, dx=dqkv[:, C:])
+	c_sink = _joint([sk.buf("ck"), sk.buf("cv")]) if DWCONV_SINK else None  # (neighbours in a flat buffer: the kernel adds into both at once)
+	_, dckv = dwconv_bwd(dkv1, qkv[:, C:], ckv, Bn, H, W, 2 * C, ks, stride, pad, dx=dqkv[:, C:], dw_out=c_sink)
 	# the stacked weight / bias gradients go straight into the three neighbouring sinks where there are such; slices of
 	# a gradient whose sinks are apart (or absent) are added by hand (or handed to autograd)
 	w_sink = _joint([sk.buf("wq"), sk.buf("wk"), sk.buf("wv")])
@@ -1661,12 +1668,13 @@ def _conv_attn_backward(dy2, x2, qkv, kv1, o, lse, wqkv, ckv, wo, geom, Skv, sk,
 		return out
 	gw = hand_out(("wq", "wk", "wv"), w_sink, dw3)
 	gb = hand_out(("bq", "bk", "bv"), b_sink, db3)
+	gc = hand_out(("ck", "cv"), c_sink, dckv)
 	dx = None
 	if need_dx:
 		# dx = [dq | dk | dv] @ [Wq; Wk; Wv]: the weight as an MN-major operand (row n of the stacked weight is k-index n)
 		dx = torch.empty((x2.shape[0], C), dtype=x2.dtype, device=x2.device)
 		gemm(dqkv, wqkv, dx, x2.shape[0], C, 3 * C, 3 * C, C, C, b_layout=L.MN_MAJOR)
-	return dx, gw, gb, dckv, sk.ret("wo", dwo), sk.ret("bo", dbo)
+	return dx, gw, gb, gc, sk.ret("wo", dwo), sk.ret("bo", dbo)
 
 
 class ConvAttentionFn(torch.autograd.Function):
@@ -1703,14 +1711,14 @@ class ConvAttentionFn(torch.autograd.Function):
 		x2, qkv, kv1, o, lse, wq, wk, wv, ck, cv, wo, wqkv, ckv = ctx.saved_tensors
 		(Bn, S, C), xdtype, (bq, bk, bv, bo), geom, dt, Skv, drop = ctx.meta
 		dy2 = _flat(cast(dy, dt))
-		sk = _Sinks(wq=wq, bq=bq, wk=wk, bk=bk, wv=wv, bv=bv, wo=wo, bo=bo)
+		sk = _Sinks(wq=wq, bq=bq, wk=wk, bk=bk, wv=wv, bv=bv, ck=ck, cv=cv, wo=wo, bo=bo)
 		with wgrad_group():
-			dx, gw, gb, dckv, gwo, gbo = _conv_attn_backward(dy2, x2, qkv, kv1, o, lse, wqkv, ckv, weight_as(wo, dt), geom, Skv, sk, ctx.needs_input_grad[0], drop)
+			dx, gw, gb, gc, gwo, gbo = _conv_attn_backward(dy2, x2, qkv, kv1, o, lse, wqkv, ckv, weight_as(wo, dt), geom, Skv, sk, ctx.needs_input_grad[0], drop)
 		if dx is not None:
 			dx = dx.reshape(Bn, S, C)
 			if dx.dtype != xdtype:
 				dx = cast(dx, xdtype)
-		return (dx, gw[0], gb[0], gw[1], gb[1], gw[2], gb[2], grad_as(dckv[:C], ck), grad_as(dckv[C:], cv), gwo, gbo, None)
+		return (dx, gw[0], gb[0], gw[1], gb[1], gw[2], gb[2], gc[0], gc[1], gwo, gbo, None)
 
 
 class CvTBlockFn(torch.autograd.Function):
@@ -1758,7 +1766,7 @@ class CvTBlockFn(torch.autograd.Function):
 			n1w, wq, wk, wv, ck, cv, wo, ls1, n2w, w1, w2, ls2) = ctx.saved_tensors
 		(Bn, S, C), xdtype, (n1b, bq, bk, bv, bo, n2b, b1, b2), cfg, dt, geom, Skv = ctx.meta
 		kind, eps, unit_offset, H, W, n_head, ks, stride, pad, act, gated = cfg
-		sk = _Sinks(n1w=n1w, n1b=n1b, wq=wq, bq=bq, wk=wk, bk=bk, wv=wv, bv=bv, wo=wo, bo=bo, n2w=n2w, n2b=n2b, w1=w1, b1=b1, w2=w2, b2=b2)
+		sk = _Sinks(n1w=n1w, n1b=n1b, wq=wq, bq=bq, wk=wk, bk=bk, wv=wv, bv=bv, ck=ck, cv=cv, wo=wo, bo=bo, n2w=n2w, n2b=n2b, w1=w1, b1=b1, w2=w2, b2=b2)
 		dx2 = _flat(cast(dy, dt))
 		with wgrad_group():  # (the block's four weight-gradient products leave together at the end)
 			# feed-forward branch
@@ -1768,12 +1776,12 @@ class CvTBlockFn(torch.autograd.Function):
 			dx1, dn2w, dn2b = norm_bwd(dn2, x1, f32(n2w), mean2, rstd2, kind, unit_offset, dres=dx2, dw_out=sk.buf("n2w"), db_out=sk.buf("n2b"))
 			# attention branch
 			dbr1, dls1 = layerscale_bwd(dx1, br1, f32(ls1)) if ls1 is not None else (dx1, None)
-			dn1, gw, gb, dckv, gwo, gbo = _conv_attn_backward(dbr1, n1, qkv, kv1, o, lse, wqkv, ckv, weight_as(wo, dt), geom, Skv, sk)
+			dn1, gw, gb, gc, gwo, gbo = _conv_attn_backward(dbr1, n1, qkv, kv1, o, lse, wqkv, ckv, weight_as(wo, dt), geom, Skv, sk)
 			dx0, dn1w, dn1b = norm_bwd(dn1, x0, f32(n1w), mean1, rstd1, kind, unit_offset, dres=dx1, dw_out=sk.buf("n1w"), db_out=sk.buf("n1b"))
 		dx0 = dx0.reshape(Bn, S, C)
 		if dx0.dtype != xdtype:
 			dx0 = cast(dx0, xdtype)
-		return (dx0, sk.ret("n1w", dn1w), sk.ret("n1b", dn1b), gw[0], gb[0], gw[1], gb[1], gw[2], gb[2], grad_as(dckv[:C], ck), grad_as(dckv[C:], cv),
+		return (dx0, sk.ret("n1w", dn1w), sk.ret("n1b", dn1b), gw[0], gb[0], gw[1], gb[1], gw[2], gb[2], gc[0], gc[1],
 			gwo, gbo, grad_as(dls1, ls1), sk.ret("n2w", dn2w), sk.ret("n2b", dn2b), sk.ret("w1", dw1), sk.ret("b1", db1), sk.ret("w2", dw2), sk.ret("b2", db2),
 			grad_as(dls2, ls2), None)
 
