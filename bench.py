@@ -183,17 +183,20 @@ def build_workload(name, dropout, dev, lr=1e-4, pipelined=True, bf16_buckets=Fal
 	else:
 		model = ViT(make_config(c, dropout)).to(dev)
 	trainer = dp.Trainer(model, lr=lr, weight_decay=0.05, pipelined_step=pipelined, bf16_buckets=bf16_buckets)
+	if teacher is not None:
+		from vit_amd.models.teacher import TeacherBeside
+		beside = TeacherBeside(teacher)  # (the teacher's forward runs on a stream of its own beside the student's)
 
 	def loss_of(xi, yi):
 		if teacher is not None:
 			# teacher forward under no_grad on stock PyTorch-ROCm in float32, as the reference runs it (deit_trainer.py:33 there;
 			# with the BatchNorms folded: 1.3 ms at batch 512 and the reference's logits to 6e-7, where bf16 autocast with the
 			# BatchNorm modules took 4.6 ms and was 4.7e-2 off), then the fused two-head loss
-			with torch.no_grad():
-				t_logits = teacher(xi)
+			beside.start(xi)
 		with torch.autocast("cuda", dtype=torch.bfloat16):
 			if teacher is not None:
 				cls, dist_ = model(xi)
+				t_logits = beside.logits()
 				return ops.deit_dual_loss(cls, dist_, yi, t_logits, alpha=c["alpha"], tau=c["tau"])
 			return ops.cross_entropy(model(xi), yi)
 	return model, trainer, loss_of, tsrc

@@ -238,11 +238,17 @@ def test_deit_step_with_the_teacher_on_the_gpu(gpu):
 	x = torch.randn(B, 3, 32, 32, generator=gen)
 	y = torch.randint(0, 10, (B,), generator=gen)
 	xg = x.to(gpu).requires_grad_(True)
+	# the teacher beside the student's forward, on a stream of its own, as bench.py runs it; same logits as in place, bit for bit
+	from vit_amd.models.teacher import TeacherBeside
+	beside = TeacherBeside(teacher)
 	with torch.no_grad():
-		t_logits = teacher(xg.detach())
+		t_in_place = teacher(xg.detach())
+	beside.start(xg.detach())
 	with torch.autocast("cuda", dtype=torch.bfloat16):
 		cls, dist = model(xg)
+		t_logits = beside.logits()
 		loss = ops.deit_dual_loss(cls, dist, y.to(gpu), t_logits, alpha=c["alpha"], tau=c["tau"])
+	assert torch.equal(t_logits, t_in_place)
 	loss.backward()
 	sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
 	leaf = {k: v.clone().requires_grad_(True) for k, v in sd.items()}

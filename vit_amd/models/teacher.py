@@ -92,3 +92,38 @@ def frozen_teacher(depth=20, num_classes=10, state_dict=None, fold_bn=False):
 	if fold_bn:
 		fold_batchnorms(m)
 	return m
+
+
+class TeacherBeside:
+	"""The frozen teacher's forward on a stream of its own, beside whatever the caller queues next (the student's forward): the
+	two are independent until the distillation loss (deit_trainer.py:33-45 of the reference runs them one after the other), and
+	both are chains of short kernels that leave most of the chip idle.  `start(x)` queues the teacher behind everything
+	already queued on the current stream; `logits()` makes the current stream wait for it and returns its output.  Under HIP
+	graph capture (and on the CPU) the teacher simply runs in place."""
+
+	def __init__(self, teacher):
+		self.teacher = teacher
+		self.stream = None
+		self.out = None
+		self.beside = False
+
+	def start(self, x):
+		self.beside = x.is_cuda and not torch.cuda.is_current_stream_capturing()
+		if not self.beside:
+			with torch.no_grad():
+				self.out = self.teacher(x)
+			return
+		if self.stream is None or self.stream.device != x.device:
+			self.stream = torch.cuda.Stream(device=x.device)
+		main = torch.cuda.current_stream(x.device)
+		self.stream.wait_stream(main)
+		with torch.cuda.stream(self.stream), torch.no_grad():
+			self.out = self.teacher(x)
+		self.out.record_stream(main)  # (allocated on the side stream, read on the main one)
+		x.record_stream(self.stream)
+
+	def logits(self):
+		out, self.out = self.out, None
+		if self.beside:
+			torch.cuda.current_stream(out.device).wait_stream(self.stream)
+		return out
