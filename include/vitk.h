@@ -424,6 +424,17 @@ int vitk_batchnorm_fwd_ws(const void* x, const float* gamma, const float* beta, 
 int vitk_batchnorm_bwd_ws(const void* dy, const void* x, const float* gamma, const float* save_mean, const float* save_rstd,
 	void* dx, float* dgamma, float* dbeta, int64_t rows, int64_t C, int training, int dtype, void* workspace,
 	int64_t workspace_bytes, void* stream);
+/* BatchNorm2d followed by the activation of an MBConv (layers/conv.py:27-37: Conv2d -> BatchNorm2d -> act) in one pass over the
+ * tensor: y = act(batchnorm(x)) (act: a VITK_ACT_* code), and its backward from dy = the gradient behind the activation: the
+ * normalised value is formed again from x, the saved statistics, gamma and beta, so neither it nor a separate activation pass
+ * exists (three fewer passes over the tensor per pair in a training step, one tensor less to keep).  C must be a multiple of 8
+ * (bf16) / 4 (f32) and the tensors 16-byte aligned: VITK_ERR_UNSUPPORTED otherwise, nothing launched. */
+int vitk_batchnorm_act_fwd(const void* x, const float* gamma, const float* beta, float* running_mean, float* running_var,
+	void* y, float* save_mean, float* save_rstd, int64_t rows, int64_t C, float eps, float momentum, int training, int act,
+	int dtype, void* workspace, int64_t workspace_bytes, void* stream);
+int vitk_batchnorm_act_bwd(const void* dy, const void* x, const float* gamma, const float* beta, const float* save_mean,
+	const float* save_rstd, void* dx, float* dgamma, float* dbeta, int64_t rows, int64_t C, int training, int act, int dtype,
+	void* workspace, int64_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -438,6 +438,41 @@ def test_conv_attention_many_rows(gpu, dtype, dim, heads, hw, stride, B):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("act", ["gelu", "silu", "relu", "relu6"])
+@pytest.mark.parametrize("training", [True, False])
+@pytest.mark.parametrize("rows,C", [(512, 32), (20000, 256), (70, 8)])
+def test_batchnorm_with_the_activation_in_the_same_pass(gpu, dtype, act, training, rows, C):
+	"""vitk_batchnorm_act_fwd / _bwd (MBConv's Conv2d -> BatchNorm2d -> act, layers/conv.py:27-37 of the reference): against
+	float64 autograd of batch_norm followed by the activation -- output, statistics, dx, dgamma, dbeta."""
+	from oracle import vit_oracle as O
+	from vit_amd import ops
+	import vit_amd._lib as L
+	g = torch.Generator().manual_seed(rows + C)
+	x = (torch.randn(rows, C, generator=g) * 2 + 0.5).to(gpu).to(dtype)
+	da = torch.randn(rows, C, generator=g).to(gpu).to(dtype)
+	gamma = (torch.rand(C, generator=g) + 0.5).to(gpu)
+	beta = torch.randn(C, generator=g).to(gpu)
+	rm0, rv0 = torch.randn(C, generator=g) * 0.3, torch.rand(C, generator=g) + 0.5
+	rm, rv = rm0.clone().to(gpu), rv0.clone().to(gpu)
+	assert ops.batchnorm_act_fusable(x)
+	code = L.ACT_CODES[act]
+	y, mean, rstd = torch.empty_like(x), torch.empty(C, device=gpu), torch.empty(C, device=gpu)
+	ops.batchnorm_fwd(x, gamma, beta, rm, rv, y, mean, rstd, 1e-5, 0.1, training, act=code)
+	dx, dg, db = torch.empty_like(x), torch.empty(C, device=gpu), torch.empty(C, device=gpu)
+	ops.batchnorm_bwd(da, x, gamma, mean, rstd, dx, dg, db, training, act=code, beta=beta)
+	xr = x.double().cpu().requires_grad_(True)
+	gr, br = gamma.double().cpu().requires_grad_(True), beta.double().cpu().requires_grad_(True)
+	rmr, rvr = rm0.double().clone(), rv0.double().clone()
+	n = torch.nn.functional.batch_norm(xr, rmr, rvr, gr, br, training, 0.1, 1e-5)
+	yr = O.act_fwd(n, act)
+	yr.backward(da.double().cpu())
+	tol = 1e-5 if dtype == torch.float32 else 2e-2
+	assert relerr(y, yr.detach()) < tol and relerr(dx, xr.grad) < tol
+	assert relerr(dg, gr.grad) < tol and relerr(db, br.grad) < tol
+	assert relerr(rm, rmr) < 1e-5 and relerr(rv, rvr) < 1e-5
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("rows,C", [(512, 32), (8 * 1024, 64), (50000, 24), (3000, 100), (70, 8)])
 def test_batchnorm_sums_are_bit_reproducible(gpu, dtype, rows, C):
 	"""BatchNorm through the scratch buffer (vitk_batchnorm_{fwd,bwd}_ws, what the conv embedding and MBConv run): the

@@ -109,6 +109,8 @@ SIGNATURES = {
 	"vitk_batchnorm_workspace_bytes": [I64, I64],
 	"vitk_batchnorm_fwd_ws": [P, P, P, P, P, P, P, P, I64, I64, FL, FL, I, I, P, I64, P],
 	"vitk_batchnorm_bwd_ws": [P, P, P, P, P, P, P, P, I64, I64, I, I, P, I64, P],
+	"vitk_batchnorm_act_fwd": [P, P, P, P, P, P, P, P, I64, I64, FL, FL, I, I, I, P, I64, P],
+	"vitk_batchnorm_act_bwd": [P, P, P, P, P, P, P, P, P, I64, I64, I, I, I, P, I64, P],
 }
 _RESTYPES = {"vitk_strerror": c_char_p, "vitk_gemm_workspace_bytes": c_int64, "vitk_gemm_last_kernel": c_char_p, "vitk_batchnorm_workspace_bytes": c_int64}
 

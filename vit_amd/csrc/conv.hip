@@ -412,7 +412,8 @@ __global__ __launch_bounds__(256) void bn_partials_sum_kernel(const float* __res
 // The same in 16-byte channel groups (C % V == 0): workgroup = 16 channel groups x 16 row lanes.
 template <typename T, int V, int MODE>
 __global__ __launch_bounds__(256) void bn_colreduce_vec_kernel(const T* __restrict__ x, const T* __restrict__ dy, const float* __restrict__ mean,
-	const float* __restrict__ rstd, float* out0, float* out1, int64_t rows, int C, float* partials) {
+	const float* __restrict__ rstd, float* out0, float* out1, int64_t rows, int C, float* partials, const float* __restrict__ gamma = nullptr,
+	const float* __restrict__ beta = nullptr, int act = 0) {
 	__shared__ float red0[16][16 * V + 1], red1[16][16 * V + 1];
 	const int cgl = threadIdx.x & 15, rl = threadIdx.x >> 4;
 	const int cg = blockIdx.x * 16 + cgl;
@@ -421,11 +422,13 @@ __global__ __launch_bounds__(256) void bn_colreduce_vec_kernel(const T* __restri
 #pragma unroll
 	for (int j = 0; j < V; ++j) a0[j] = a1[j] = 0.f;
 	if (c0 < C) {
-		float mu[V], rs[V];
+		float mu[V], rs[V], ga[V], be[V];  // (ga, be: with a fused activation, dy is the gradient behind it and the normalised value is formed again)
 #pragma unroll
 		for (int j = 0; j < V; ++j) {
 			mu[j] = (MODE >= 1) ? mean[c0 + j] : 0.f;
 			rs[j] = (MODE == 2) ? rstd[c0 + j] : 0.f;
+			ga[j] = (MODE == 2 && act != 0) ? gamma[c0 + j] : 0.f;
+			be[j] = (MODE == 2 && act != 0) ? beta[c0 + j] : 0.f;
 		}
 		for (int64_t r = (int64_t)blockIdx.y * 16 + rl; r < rows; r += (int64_t)gridDim.y * 16) {
 			float v[V];
@@ -439,6 +442,10 @@ __global__ __launch_bounds__(256) void bn_colreduce_vec_kernel(const T* __restri
 			} else {
 				float g[V];
 				load_vec<T, V>(dy + r * C + c0, g);
+				if (act != 0) {
+#pragma unroll
+					for (int j = 0; j < V; ++j) g[j] *= act_deriv((v[j] - mu[j]) * rs[j] * ga[j] + be[j], act);
+				}
 #pragma unroll
 				for (int j = 0; j < V; ++j) {
 					a0[j] += g[j];
@@ -477,7 +484,7 @@ __global__ __launch_bounds__(256) void bn_colreduce_vec_kernel(const T* __restri
 // registers and walks rows, so the per-channel parameters are read once per thread instead of once per 16 bytes of data.
 template <typename T, int V>
 __global__ __launch_bounds__(256) void bn_apply_vec_kernel(const T* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
-	const float* __restrict__ mean, const float* __restrict__ rstd_or_var, T* __restrict__ y, int64_t rows, int C, float eps, int use_var) {
+	const float* __restrict__ mean, const float* __restrict__ rstd_or_var, T* __restrict__ y, int64_t rows, int C, float eps, int use_var, int act = 0) {
 	const int cg = blockIdx.x * 16 + (threadIdx.x & 15), rl = threadIdx.x >> 4;
 	const int c0 = cg * V;
 	if (c0 >= C) return;
@@ -493,6 +500,10 @@ __global__ __launch_bounds__(256) void bn_apply_vec_kernel(const T* __restrict__
 		load_vec<T, V>(x + r * C + c0, v);
 #pragma unroll
 		for (int j = 0; j < V; ++j) o[j] = v[j] * sc[j] + sh[j];
+		if (act != 0) {  // the activation behind the normalisation, in the same pass
+#pragma unroll
+			for (int j = 0; j < V; ++j) o[j] = act_apply(o[j], act);
+		}
 		store_vec<T, V>(y + r * C + c0, o);
 	}
 }
@@ -501,24 +512,29 @@ __global__ __launch_bounds__(256) void bn_apply_vec_kernel(const T* __restrict__
 template <typename T, int V>
 __global__ __launch_bounds__(256) void bn_bwd_apply_vec_kernel(const T* __restrict__ dy, const T* __restrict__ x, const float* __restrict__ gamma,
 	const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ dgamma, const float* __restrict__ dbeta, T* __restrict__ dx,
-	int64_t rows, int C, float inv_rows, int training) {
+	int64_t rows, int C, float inv_rows, int training, const float* __restrict__ beta = nullptr, int act = 0) {
 	const int cg = blockIdx.x * 16 + (threadIdx.x & 15), rl = threadIdx.x >> 4;
 	const int c0 = cg * V;
 	if (c0 >= C) return;
-	float A[V], K[V], D[V], mu[V];
+	float A[V], K[V], D[V], mu[V], be[V];
 #pragma unroll
 	for (int j = 0; j < V; ++j) {
 		A[j] = gamma[c0 + j] * rstd[c0 + j];
 		K[j] = training ? A[j] * rstd[c0 + j] * dgamma[c0 + j] * inv_rows : 0.f;
 		D[j] = training ? A[j] * dbeta[c0 + j] * inv_rows : 0.f;
 		mu[j] = mean[c0 + j];
+		be[j] = act != 0 ? beta[c0 + j] : 0.f;
 	}
 	for (int64_t r = (int64_t)blockIdx.y * 16 + rl; r < rows; r += (int64_t)gridDim.y * 16) {
 		float g[V], o[V];
 		load_vec<T, V>(dy + r * C + c0, g);
-		if (training) {
+		if (training || act != 0) {
 			float v[V];
 			load_vec<T, V>(x + r * C + c0, v);
+			if (act != 0) {  // dy is the gradient behind the fused activation: times its derivative at the normalised value
+#pragma unroll
+				for (int j = 0; j < V; ++j) g[j] *= act_deriv((v[j] - mu[j]) * A[j] + be[j], act);
+			}
 #pragma unroll
 			for (int j = 0; j < V; ++j) o[j] = A[j] * g[j] - K[j] * (v[j] - mu[j]) - D[j];
 		} else {
@@ -736,10 +752,16 @@ inline void bn_sum(float* partials, unsigned slabs, int64_t C, float* out0, floa
 }
 }  // namespace
 
-extern "C" int vitk_batchnorm_fwd_ws(const void* x, const float* gamma, const float* beta, float* running_mean, float* running_var, void* y, float* save_mean,
-	float* save_rstd, int64_t rows, int64_t C, float eps, float momentum, int training, int dtype, void* workspace, int64_t workspace_bytes, void* stream) {
+// act != 0: y = act(normalised x) in the same pass (16-byte channel groups only: VITK_ERR_UNSUPPORTED otherwise, nothing launched)
+static int bn_fwd_impl(const void* x, const float* gamma, const float* beta, float* running_mean, float* running_var, void* y, float* save_mean,
+	float* save_rstd, int64_t rows, int64_t C, float eps, float momentum, int training, int dtype, int act, void* workspace, int64_t workspace_bytes, void* stream) {
 	VITK_REQUIRE(x && gamma && beta && running_mean && running_var && y, VITK_ERR_NULL);
 	VITK_REQUIRE(rows > 0 && C > 0 && C < (1 << 30), VITK_ERR_SHAPE);
+	VITK_REQUIRE(act >= VITK_ACT_NONE && act <= VITK_ACT_RELU6, VITK_ERR_UNSUPPORTED);
+	if (act != 0) {
+		const int v = dtype == VITK_BF16 ? 8 : 4;
+		if (C % v != 0 || !vitk_aligned(x, 16) || !vitk_aligned(y, 16)) return VITK_ERR_UNSUPPORTED;
+	}
 	hipStream_t st = (hipStream_t)stream;
 	const int64_t n = rows * C;
 	if (!training) {
@@ -748,7 +770,7 @@ extern "C" int vitk_batchnorm_fwd_ws(const void* x, const float* gamma, const fl
 			constexpr int V = VecOf<T>::N;
 			if (C % V == 0 && vitk_aligned(x, 16) && vitk_aligned(y, 16))
 				hipLaunchKernelGGL((bn_apply_vec_kernel<T, V>), colgrid_vec(rows, (int)C / V), dim3(256), 0, st, (const T*)x, gamma, beta, running_mean, running_var, (T*)y, rows,
-					(int)C, eps, 1);
+					(int)C, eps, 1, act);
 			else
 				hipLaunchKernelGGL((bn_apply_kernel<T>), dim3(vitk_stream_grid(n, 256)), dim3(256), 0, st, (const T*)x, gamma, beta, running_mean, running_var, (T*)y, n, (int)C,
 					eps, 1);
@@ -773,7 +795,7 @@ extern "C" int vitk_batchnorm_fwd_ws(const void* x, const float* gamma, const fl
 			hipLaunchKernelGGL((bn_colreduce_vec_kernel<T, V, 1>), vg, dim3(256), 0, st, (const T*)x, (const T*)nullptr, save_mean, nullptr, save_rstd, nullptr, rows, (int)C, part);
 			bn_sum(part, vg.y, C, save_rstd, nullptr, st);
 			hipLaunchKernelGGL((bn_finalize_kernel<1>), dim3(fg), dim3(256), 0, st, save_mean, save_rstd, running_mean, running_var, rows, (int)C, eps, momentum);
-			hipLaunchKernelGGL((bn_apply_vec_kernel<T, V>), vg, dim3(256), 0, st, (const T*)x, gamma, beta, save_mean, save_rstd, (T*)y, rows, (int)C, eps, 0);
+			hipLaunchKernelGGL((bn_apply_vec_kernel<T, V>), vg, dim3(256), 0, st, (const T*)x, gamma, beta, save_mean, save_rstd, (T*)y, rows, (int)C, eps, 0, act);
 			VITK_CHECK_LAUNCH();
 			return VITK_OK;
 		}
@@ -790,15 +812,33 @@ extern "C" int vitk_batchnorm_fwd_ws(const void* x, const float* gamma, const fl
 	});
 }
 
+extern "C" int vitk_batchnorm_fwd_ws(const void* x, const float* gamma, const float* beta, float* running_mean, float* running_var, void* y, float* save_mean,
+	float* save_rstd, int64_t rows, int64_t C, float eps, float momentum, int training, int dtype, void* workspace, int64_t workspace_bytes, void* stream) {
+	return bn_fwd_impl(x, gamma, beta, running_mean, running_var, y, save_mean, save_rstd, rows, C, eps, momentum, training, dtype, 0, workspace, workspace_bytes, stream);
+}
+
+extern "C" int vitk_batchnorm_act_fwd(const void* x, const float* gamma, const float* beta, float* running_mean, float* running_var, void* y, float* save_mean,
+	float* save_rstd, int64_t rows, int64_t C, float eps, float momentum, int training, int act, int dtype, void* workspace, int64_t workspace_bytes, void* stream) {
+	return bn_fwd_impl(x, gamma, beta, running_mean, running_var, y, save_mean, save_rstd, rows, C, eps, momentum, training, dtype, act, workspace, workspace_bytes, stream);
+}
+
 extern "C" int vitk_batchnorm_fwd(const void* x, const float* gamma, const float* beta, float* running_mean, float* running_var, void* y, float* save_mean,
 	float* save_rstd, int64_t rows, int64_t C, float eps, float momentum, int training, int dtype, void* stream) {
 	return vitk_batchnorm_fwd_ws(x, gamma, beta, running_mean, running_var, y, save_mean, save_rstd, rows, C, eps, momentum, training, dtype, nullptr, 0, stream);
 }
 
-extern "C" int vitk_batchnorm_bwd_ws(const void* dy, const void* x, const float* gamma, const float* save_mean, const float* save_rstd, void* dx, float* dgamma,
-	float* dbeta, int64_t rows, int64_t C, int training, int dtype, void* workspace, int64_t workspace_bytes, void* stream) {
+// act != 0: dy is the gradient behind the activation that bn_fwd_impl fused; its derivative is taken at the normalised value, formed
+// again from x, the statistics, gamma and beta (16-byte channel groups only)
+static int bn_bwd_impl(const void* dy, const void* x, const float* gamma, const float* beta, const float* save_mean, const float* save_rstd, void* dx, float* dgamma,
+	float* dbeta, int64_t rows, int64_t C, int training, int dtype, int act, void* workspace, int64_t workspace_bytes, void* stream) {
 	VITK_REQUIRE(dy && x && gamma && save_mean && save_rstd && dx && dgamma && dbeta, VITK_ERR_NULL);
 	VITK_REQUIRE(rows > 0 && C > 0 && C < (1 << 30), VITK_ERR_SHAPE);
+	VITK_REQUIRE(act >= VITK_ACT_NONE && act <= VITK_ACT_RELU6, VITK_ERR_UNSUPPORTED);
+	if (act != 0) {
+		VITK_REQUIRE(beta != nullptr, VITK_ERR_NULL);
+		const int v = dtype == VITK_BF16 ? 8 : 4;
+		if (C % v != 0 || !vitk_aligned(x, 16) || !vitk_aligned(dy, 16) || !vitk_aligned(dx, 16)) return VITK_ERR_UNSUPPORTED;
+	}
 	hipStream_t st = (hipStream_t)stream;
 	const int64_t n = rows * C;
 	hipError_t e = vitk_zero_f32(dgamma, C, st);
@@ -810,10 +850,11 @@ extern "C" int vitk_batchnorm_bwd_ws(const void* dy, const void* x, const float*
 		if (C % V == 0 && vitk_aligned(x, 16) && vitk_aligned(dy, 16) && vitk_aligned(dx, 16)) {
 			const dim3 vg = colgrid_vec(rows, (int)C / V);
 			float* part = bn_partials(workspace, workspace_bytes, vg.y, C);
-			hipLaunchKernelGGL((bn_colreduce_vec_kernel<T, V, 2>), vg, dim3(256), 0, st, (const T*)x, (const T*)dy, save_mean, save_rstd, dbeta, dgamma, rows, (int)C, part);
+			hipLaunchKernelGGL((bn_colreduce_vec_kernel<T, V, 2>), vg, dim3(256), 0, st, (const T*)x, (const T*)dy, save_mean, save_rstd, dbeta, dgamma, rows, (int)C, part,
+				gamma, beta, act);
 			bn_sum(part, vg.y, C, dbeta, dgamma, st);
 			hipLaunchKernelGGL((bn_bwd_apply_vec_kernel<T, V>), vg, dim3(256), 0, st, (const T*)dy, (const T*)x, gamma, save_mean, save_rstd, dgamma,
-				dbeta, (T*)dx, rows, (int)C, 1.0f / (float)rows, training);
+				dbeta, (T*)dx, rows, (int)C, 1.0f / (float)rows, training, beta, act);
 			VITK_CHECK_LAUNCH();
 			return VITK_OK;
 		}
@@ -825,6 +866,16 @@ extern "C" int vitk_batchnorm_bwd_ws(const void* dy, const void* x, const float*
 		VITK_CHECK_LAUNCH();
 		return VITK_OK;
 	});
+}
+
+extern "C" int vitk_batchnorm_bwd_ws(const void* dy, const void* x, const float* gamma, const float* save_mean, const float* save_rstd, void* dx, float* dgamma,
+	float* dbeta, int64_t rows, int64_t C, int training, int dtype, void* workspace, int64_t workspace_bytes, void* stream) {
+	return bn_bwd_impl(dy, x, gamma, nullptr, save_mean, save_rstd, dx, dgamma, dbeta, rows, C, training, dtype, 0, workspace, workspace_bytes, stream);
+}
+
+extern "C" int vitk_batchnorm_act_bwd(const void* dy, const void* x, const float* gamma, const float* beta, const float* save_mean, const float* save_rstd, void* dx,
+	float* dgamma, float* dbeta, int64_t rows, int64_t C, int training, int act, int dtype, void* workspace, int64_t workspace_bytes, void* stream) {
+	return bn_bwd_impl(dy, x, gamma, beta, save_mean, save_rstd, dx, dgamma, dbeta, rows, C, training, dtype, act, workspace, workspace_bytes, stream);
 }
 
 extern "C" int vitk_batchnorm_bwd(const void* dy, const void* x, const float* gamma, const float* save_mean, const float* save_rstd, void* dx, float* dgamma,

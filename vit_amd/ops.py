@@ -1477,20 +1477,37 @@ def dropout(x, p):
 # CvT: conv token embedding, conv-projection attention, mean pool
 # --------------------------------------------------------------------------------------------------
 
-def batchnorm_fwd(x, gamma, beta, running_mean, running_var, y, save_mean, save_rstd, eps, momentum, training):
+BN_ACT_FUSED = os.environ.get("VITK_BN_ACT_FUSED", "1") != "0"  # A-B switch: BatchNorm + activation of an MBConv in one pass
+
+
+def batchnorm_act_fusable(x):
+	"""Whether batchnorm_fwd / batchnorm_bwd take `act` for x [rows, C] (16-byte channel groups)."""
+	return BN_ACT_FUSED and x.shape[1] % (8 if x.dtype == torch.bfloat16 else 4) == 0 and x.is_contiguous()
+
+
+def batchnorm_fwd(x, gamma, beta, running_mean, running_var, y, save_mean, save_rstd, eps, momentum, training, act=L.ACT_NONE):
 	"""vitk_batchnorm_fwd_ws over x [rows, C]: the column sums pass through the GEMM scratch buffer and are added in a fixed
-	order (bit-reproducible batch statistics)."""
+	order (bit-reproducible batch statistics).  act: y = act(batchnorm(x)) in the same pass (batchnorm_act_fusable)."""
 	rows, C = x.shape
 	ws = gemm_workspace(x.device)
 	assert ws.numel() >= L.load().vitk_batchnorm_workspace_bytes(rows, C), "scratch buffer smaller than the BatchNorm partial sums"
+	if act != L.ACT_NONE:
+		L.check(L.load().vitk_batchnorm_act_fwd(L.ptr(x), L.ptr(gamma), L.ptr(beta), L.ptr(running_mean), L.ptr(running_var), L.ptr(y), L.ptr(save_mean),
+			L.ptr(save_rstd), rows, C, eps, momentum, int(training), act, L.dtype_code(x.dtype), ws.data_ptr(), ws.numel(), L.stream()))
+		return
 	L.check(L.load().vitk_batchnorm_fwd_ws(L.ptr(x), L.ptr(gamma), L.ptr(beta), L.ptr(running_mean), L.ptr(running_var), L.ptr(y), L.ptr(save_mean), L.ptr(save_rstd),
 		rows, C, eps, momentum, int(training), L.dtype_code(x.dtype), ws.data_ptr(), ws.numel(), L.stream()))
 
 
-def batchnorm_bwd(dy, x, gamma, save_mean, save_rstd, dx, dgamma, dbeta, training):
+def batchnorm_bwd(dy, x, gamma, save_mean, save_rstd, dx, dgamma, dbeta, training, act=L.ACT_NONE, beta=None):
+	"""act (with beta): dy is the gradient behind the activation that batchnorm_fwd fused."""
 	rows, C = x.shape
 	ws = gemm_workspace(x.device)
 	assert ws.numel() >= L.load().vitk_batchnorm_workspace_bytes(rows, C), "scratch buffer smaller than the BatchNorm partial sums"
+	if act != L.ACT_NONE:
+		L.check(L.load().vitk_batchnorm_act_bwd(L.ptr(dy), L.ptr(x), L.ptr(gamma), L.ptr(beta), L.ptr(save_mean), L.ptr(save_rstd), L.ptr(dx), L.ptr(dgamma),
+			L.ptr(dbeta), rows, C, int(training), act, L.dtype_code(x.dtype), ws.data_ptr(), ws.numel(), L.stream()))
+		return
 	L.check(L.load().vitk_batchnorm_bwd_ws(L.ptr(dy), L.ptr(x), L.ptr(gamma), L.ptr(save_mean), L.ptr(save_rstd), L.ptr(dx), L.ptr(dgamma), L.ptr(dbeta),
 		rows, C, int(training), L.dtype_code(x.dtype), ws.data_ptr(), ws.numel(), L.stream()))
 
@@ -1814,11 +1831,11 @@ class MBConvFn(torch.autograd.Function):
 			R = Bn * S
 			t0 = xc.reshape(R, Cin)
 
-		def bn(h, g, b, rm, rv):
+		def bn(h, g, b, rm, rv, fused_act=L.ACT_NONE):
 			y = torch.empty_like(h)
 			mean = torch.empty(h.shape[1], dtype=torch.float32, device=h.device)
 			rstd = torch.empty(h.shape[1], dtype=torch.float32, device=h.device)
-			batchnorm_fwd(h, f32(g), f32(b), rm, rv, y, mean, rstd, eps, momentum, training)
+			batchnorm_fwd(h, f32(g), f32(b), rm, rv, y, mean, rstd, eps, momentum, training, act=fused_act)
 			return y, mean, rstd
 
 		def act_fwd(u):
@@ -1826,11 +1843,22 @@ class MBConvFn(torch.autograd.Function):
 			L.check(lib.vitk_act_fwd(L.ptr(u), L.ptr(a), u.numel(), act, dtc, L.stream()))
 			return a
 		h1 = linear_fwd(t0, weight_as(w1, dt).reshape(hid, Cin))
-		n1, m1, r1 = bn(h1, g1, b1, rm1, rv1)
-		a1 = act_fwd(n1)
+		# BatchNorm + activation in one pass where the channels allow (n1 / n2, the normalised values, then do not exist: the
+		# backward forms them again inside the BatchNorm backward kernels)
+		fused = act != L.ACT_NONE and batchnorm_act_fusable(h1)
+		if fused:
+			a1, m1, r1 = bn(h1, g1, b1, rm1, rv1, act)
+			n1 = None
+		else:
+			n1, m1, r1 = bn(h1, g1, b1, rm1, rv1)
+			a1 = act_fwd(n1)
 		h2, S2 = dwconv_fwd(a1, weight_as(wd, dt), Bn, H, W, hid, 3, stride, 1)
-		n2, m2, r2 = bn(h2, g2, b2, rm2, rv2)
-		a2 = act_fwd(n2)
+		if fused:
+			a2, m2, r2 = bn(h2, g2, b2, rm2, rv2, act)
+			n2 = None
+		else:
+			n2, m2, r2 = bn(h2, g2, b2, rm2, rv2)
+			a2 = act_fwd(n2)
 		h3 = linear_fwd(a2, weight_as(w3, dt).reshape(Cout, hid))
 		n3, m3, r3 = bn(h3, g3, b3, rm3, rv3)
 		if use_res:
@@ -1843,11 +1871,13 @@ class MBConvFn(torch.autograd.Function):
 			y = n3.reshape(Bn, Ho * Wo, Cout)
 		ctx.save_for_backward(t0, h1, n1, a1, h2, n2, a2, h3, m1, r1, m2, r2, m3, r3, w1, wd, w3, g1, g2, g3)
 		ctx.meta = (x.shape, x.dtype, (b1, b2, b3), cfg, dt, (Bn, Cin, H, W, hid, Cout, Ho, Wo))
+		ctx.fused = fused
 		return y
 
 	@staticmethod
 	def backward(ctx, dy):
 		t0, h1, n1, a1, h2, n2, a2, h3, m1, r1, m2, r2, m3, r3, w1, wd, w3, g1, g2, g3 = ctx.saved_tensors
+		fused = ctx.fused
 		xshape, xdtype, (b1, b2, b3), cfg, dt, (Bn, Cin, H, W, hid, Cout, Ho, Wo) = ctx.meta
 		stride, act, use_res, eps, momentum, training = cfg[:6]
 		hw = cfg[6] if len(cfg) > 6 else None
@@ -1860,11 +1890,11 @@ class MBConvFn(torch.autograd.Function):
 		else:
 			d3 = dyc.reshape(Bn * Ho * Wo, Cout)
 
-		def bn_bwd(dn, h, g, mean, rstd):
+		def bn_bwd(dn, h, g, mean, rstd, fused_act=L.ACT_NONE, b=None):
 			dh = torch.empty_like(h)
 			dg = torch.empty(h.shape[1], dtype=torch.float32, device=h.device)
 			db = torch.empty(h.shape[1], dtype=torch.float32, device=h.device)
-			batchnorm_bwd(dn, h, f32(g), mean, rstd, dh, dg, db, training)
+			batchnorm_bwd(dn, h, f32(g), mean, rstd, dh, dg, db, training, act=fused_act, beta=f32(b) if b is not None else None)
 			return dh, dg, db
 
 		def act_bwd(da, pre):
@@ -1874,11 +1904,15 @@ class MBConvFn(torch.autograd.Function):
 		dh3, dg3, db3 = bn_bwd(d3, h3, g3, m3, r3)
 		dw3 = linear_wgrad(dh3, a2).reshape(w3.shape)
 		da2 = linear_dgrad(dh3, weight_as(w3, dt).reshape(Cout, hid))
-		dn2 = act_bwd(da2, n2)
-		dh2, dg2, db2 = bn_bwd(dn2, h2, g2, m2, r2)
+		if fused:
+			dh2, dg2, db2 = bn_bwd(da2, h2, g2, m2, r2, act, b2)
+		else:
+			dh2, dg2, db2 = bn_bwd(act_bwd(da2, n2), h2, g2, m2, r2)
 		da1, dwd = dwconv_bwd(dh2, a1, weight_as(wd, dt), Bn, H, W, hid, 3, stride, 1)
-		dn1 = act_bwd(da1, n1)
-		dh1, dg1, db1 = bn_bwd(dn1, h1, g1, m1, r1)
+		if fused:
+			dh1, dg1, db1 = bn_bwd(da1, h1, g1, m1, r1, act, b1)
+		else:
+			dh1, dg1, db1 = bn_bwd(act_bwd(da1, n1), h1, g1, m1, r1)
 		dw1 = linear_wgrad(dh1, t0).reshape(w1.shape)
 		dx = None
 		if ctx.needs_input_grad[0]:
