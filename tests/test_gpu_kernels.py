@@ -362,6 +362,8 @@ GROUPS = {
 	# token counts that differ (one K slice for the short one), ragged widths, more products than one launch takes
 	"mixed_lengths": [(20000, 200, 136, True, True), (1024, 72, 264, True, False), (33280, 192, 576, False, False), (2048, 64, 64, True, True)],
 	"twelve": [(8192 + 64 * i, 64 + 8 * i, 192, i % 2 == 0, i % 3 != 0) for i in range(12)],
+	# more output tiles than the launch has workgroup slots (8 x 90 tiles of 128 x 128): one K slice each, several rounds
+	"many_tiles": [(1024 + 64 * i, 1152, 1280, i % 2 == 0, i % 2 == 1) for i in range(8)],
 	# products the grouped kernel does not take ride along (large tiles; few rows; float32 operands are a separate case below)
 	"with_others": [(33280, 192, 192, True, True), (197 * 64, 2304, 768, True, True), (16384, 192, 576, True, False), (512, 10, 192, True, True)],
 }
@@ -395,7 +397,7 @@ def test_gemm_group_matches_separate_launches(gpu, name):
 	assert len(held) == len(probs)
 	descs = (L.GemmDesc * len(held))(*[h[0] for h in held])
 	L.check(L.load().vitk_gemm_group(descs, len(held), L.stream()))
-	if name in ("vit_tiny_block", "cvt_stage1_block", "cvt_stage3_block", "mixed_lengths", "twelve"):
+	if name in ("vit_tiny_block", "cvt_stage1_block", "cvt_stage3_block", "mixed_lengths", "twelve", "many_tiles"):
 		assert L.load().vitk_gemm_last_kernel().decode() == "gemm_bf16_group_kernel"
 	for (dw1, db1), (dwg, dbg), (dy, x, dyr, xr, bias, acc) in zip(single, grouped, probs):
 		ref = dyr.t() @ xr + (start if acc else 0.0)

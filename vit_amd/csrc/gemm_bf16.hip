@@ -892,8 +892,13 @@ int vitk_gemm_bf16_group128(const vitk_gemm_desc* const* ds, int n, hipStream_t 
 	}
 	// one K-slice length for all problems (every workgroup then has the same amount of work), the shortest with which the
 	// launch fits the chip at two workgroups per CU and no problem has more than 64 slices
-	int64_t kt_per = std::max<int64_t>(8, vitk_cdiv(work, 512));
-	for (;; ++kt_per) {
+	// (many tiles: the slices grow until every problem is one slice, and the launch simply has more rounds)
+	int64_t kt_per = std::max<int64_t>(8, vitk_cdiv(work, 512)), longest = 0, ws_bytes = ds[0]->workspace_bytes;
+	for (int i = 0; i < n; ++i) {
+		longest = std::max(longest, ktiles[i]);
+		ws_bytes = std::min(ws_bytes, ds[i]->workspace_bytes);
+	}
+	for (; kt_per < longest; ++kt_per) {
 		int64_t wgs = 0, most = 0;
 		for (int i = 0; i < n; ++i) {
 			const int64_t s = vitk_cdiv(ktiles[i], kt_per);
@@ -928,7 +933,7 @@ int vitk_gemm_bf16_group128(const vitk_gemm_desc* const* ds, int n, hipStream_t 
 	ga.first[n] = wg0;
 	ga.n = n;
 	rg.first[rg.n] = row0;
-	if (used > ds[0]->workspace_bytes) return VITK_ERR_UNSUPPORTED;
+	if (used > ws_bytes) return VITK_ERR_UNSUPPORTED;
 	vitk_last_gemm_kernel = "gemm_bf16_group_kernel";
 	static bool attr_set = false;
 	if (!attr_set) {
