@@ -148,7 +148,7 @@ int vitk_gemm_leave_cus_free(int on);
 /* 1 if vitk_gemm would run this problem on the bf16 MFMA kernel, 0 if on the generic float32-MFMA kernel. */
 int vitk_gemm_uses_bf16_mfma(const vitk_gemm_desc* desc);
 /* Name of the kernel family the calling thread's last vitk_gemm launched ("gemm_bf16_p8_kernel", "gemm_bf16_p8w_kernel",
- * "gemm_bf16_t128_kernel", "gemm_bf16_256_kernel", "gemm_bf16_kernel", "gemm_bf16_group_kernel", "gemm_generic_kernel"; "" before the first call): the
+ * "gemm_bf16_t128_kernel", "gemm_bf16_256_kernel", "gemm_bf16_kernel", "gemm_bf16_deep_kernel", "gemm_bf16_group_kernel", "gemm_generic_kernel"; "" before the first call): the
  * names a kernel trace shows, for reports that put measured launch times next to a profile.  No counterpart in the
  * reference (torch.nn.functional.linear picks its kernel out of sight, layers/transformers.py:46-54). */
 const char* vitk_gemm_last_kernel(void);

@@ -700,6 +700,7 @@ int launch_deep(const BfArgs& a, dim3 grid, hipStream_t st) {
 		if (e != hipSuccess) return VITK_ERR_HIP - (int)e;
 		attr_set = true;
 	}
+	vitk_last_gemm_kernel = "gemm_bf16_deep_kernel";
 	hipLaunchKernelGGL((gemm_bf16_deep_kernel<AL, BL, TOUT>), grid, dim3(512), DEEP_LDS_BYTES, st, a);
 	VITK_CHECK_LAUNCH();
 	return VITK_OK;
