@@ -526,7 +526,8 @@ def test_norms(gpu, dtype, kind, rows, d):
 	(70, 12, 65, 65, 64), (67, 9, 40, 24, 64),  # these two: more (batch, head) pairs than CUs (several pairs per workgroup, ragged last workgroup)
 	# key-blocked online-softmax kernels (bf16): the conv + attention hybrid's stages, a CvT-sized first stage, ragged blocks, every head-size class
 	(2, 4, 784, 784, 12), (2, 4, 196, 196, 24), (1, 2, 3136, 3136, 64), (1, 2, 300, 77, 40), (1, 3, 129, 64, 8), (1, 1, 64, 64, 4), (2, 2, 257, 513, 48), (1, 2, 5, 1, 20),
-	(1, 2, 1, 130, 16), (1, 2, 260, 260, 64)])
+	(1, 2, 1, 130, 16), (1, 2, 260, 260, 64),
+	(2, 3, 200, 250, 28), (1, 5, 600, 256, 12), (3, 2, 70, 129, 32)])  # one-pass backward of the key-blocked family (small heads, at most 256 keys): ragged key and query blocks
 def test_attention(gpu, dtype, B, h, Sq, Skv, dh):
 	from vit_amd import ops
 	d = h * dh
@@ -558,7 +559,7 @@ def test_attention(gpu, dtype, B, h, Sq, Skv, dh):
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("B,h,Sq,Skv,dh,p", [(2, 12, 197, 197, 64, 0.3), (2, 3, 65, 65, 64, 0.1), (2, 2, 50, 13, 24, 0.3), (1, 2, 300, 300, 64, 0.5), (2, 2, 64, 16, 32, 0.3),
 	(70, 12, 65, 65, 64, 0.3), (67, 9, 40, 24, 64, 0.2),  # these two: more (batch, head) pairs than CUs, so a workgroup walks several pairs
-	(2, 4, 784, 784, 12, 0.3), (2, 4, 196, 196, 24, 0.2), (1, 2, 300, 77, 40, 0.3), (1, 2, 520, 520, 64, 0.1), (1, 3, 129, 64, 8, 0.5)])  # key-blocked kernels
+	(2, 4, 784, 784, 12, 0.3), (2, 4, 196, 196, 24, 0.2), (1, 2, 300, 77, 40, 0.3), (1, 2, 520, 520, 64, 0.1), (1, 3, 129, 64, 8, 0.5), (2, 3, 200, 250, 28, 0.3)])  # key-blocked kernels
 def test_attention_dropout(gpu, dtype, B, h, Sq, Skv, dh, p):
 	"""Attention with dropout on the probabilities (the reference's training path, layers/attention.py:41,86): the
 	kernels' mask is regenerated on the CPU and handed to the oracle, so forward and all three gradients are compared

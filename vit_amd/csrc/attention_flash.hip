@@ -16,6 +16,8 @@
 //   dK / dV (key on the lane):  S = Q K^T, dP = dO V^T, dV^T = dO^T P, dK^T = Q^T dS over all query blocks
 // The backward is two kernels so that no gradient needs a cross-workgroup sum.  Dropout on the probabilities (DROP): the
 // normaliser and lse are those of the undropped softmax; O, dP and the P that feeds dV carry the mask.
+#include <cstdlib>
+
 #include "attention.h"
 
 namespace {
@@ -415,11 +417,206 @@ __global__ __launch_bounds__(256) void attn_flash_dkv_kernel(AttnArgs a) {
 	}
 }
 
+// ---- backward in ONE pass (small heads): lse (log2 units) and delta = rowsum(dO o O) first ... --------------------------------
+// one thread per (batch, query, head), head fastest: neighbouring threads read neighbouring head slices of one token row
+__global__ __launch_bounds__(256) void attn_flash_delta_kernel(AttnArgs a) {
+	const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+	const int64_t n_bh = (int64_t)a.B * a.n_head;
+	if (idx >= n_bh * a.Sq) return;
+	const int h = (int)(idx % a.n_head);
+	const int64_t bq = idx / a.n_head;
+	const int q = (int)(bq % a.Sq), b = (int)(bq / a.Sq);
+	const bf16_t* op = reinterpret_cast<const bf16_t*>(a.out) + ((int64_t)b * a.Sq + q) * a.ldo + h * a.dh;
+	const bf16_t* gp = reinterpret_cast<const bf16_t*>(a.dout) + ((int64_t)b * a.Sq + q) * a.ldo + h * a.dh;
+	float delta = 0.f;
+	for (int d = 0; d < a.dh; d += 4) {
+		const bf16x4 o4 = *reinterpret_cast<const bf16x4*>(op + d), g4 = *reinterpret_cast<const bf16x4*>(gp + d);
+#pragma unroll
+		for (int j = 0; j < 4; ++j) delta += (float)o4[j] * (float)g4[j];
+	}
+	const int64_t bh = (int64_t)b * a.n_head + h;
+	a.bwd_scratch[bh * a.Sq + q] = a.lse[bh * a.Sq + q] * LOG2E;
+	a.bwd_scratch[(n_bh + bh) * a.Sq + q] = delta;
+}
+
+// ... then one workgroup per (batch, head): keys in blocks of 64 (outer loop: a wave owns 16 keys, their K / V fragments and
+// dK / dV accumulators in registers, key on the lane as in the dK / dV kernel), queries in blocks of 64 (inner loop).  S, dP, P and
+// dS of a (key block, query block) pair are formed ONCE -- the two-kernel form computes them twice, and at head size 12 that
+// softmax arithmetic, not the matrix pipe, is what the time goes into.  dS goes through an LDS image [key][query] (the V image's
+// space: V lives in registers by then) and comes back by transposing reads as the operand of dQ^T += K^T dS^T, query on the
+// lane; dQ of all the head's queries accumulates in a float32 LDS array [Sq][dh] (a wave only ever touches the rows of its own
+// 16 queries of a block: plain read-add-write), and leaves once at the end.  No gradient needs a cross-workgroup sum.
+template <int KS, int NDT, bool DROP>
+__global__ __launch_bounds__(256) void attn_flash_bwd1_kernel(AttnArgs a) {
+	if constexpr (DROP) attn_enter(a);
+	extern __shared__ __attribute__((aligned(16))) char smem[];
+	char *Ks = smem, *Vs = smem + IMG, *Qs = smem + 2 * IMG, *Gs = smem + 3 * IMG;
+	char* DSs = Vs;
+	float* lse_s = reinterpret_cast<float*>(smem + 4 * IMG);
+	float* delta_s = lse_s + 64;
+	uint32_t* rk_s = reinterpret_cast<uint32_t*>(delta_s + 64);
+	float* dq_s = reinterpret_cast<float*>(smem + 4 * IMG + 3 * 64 * 4);  // [Sq][dh]
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4;
+	const int bh = blockIdx.x, b = bh / a.n_head, h = bh - b * a.n_head;
+	const int n_bh = a.B * a.n_head;
+	const int dh4 = a.dh >> 2;
+	const bf16_t* qb = reinterpret_cast<const bf16_t*>(a.q) + (int64_t)b * a.Sq * a.ldq + h * a.dh;
+	const bf16_t* gb = reinterpret_cast<const bf16_t*>(a.dout) + (int64_t)b * a.Sq * a.ldo + h * a.dh;
+	const bf16_t* kb = reinterpret_cast<const bf16_t*>(a.k) + (int64_t)b * a.Skv * a.ldk + h * a.dh;
+	const bf16_t* vb = reinterpret_cast<const bf16_t*>(a.v) + (int64_t)b * a.Skv * a.ldv + h * a.dh;
+	zero_lds(smem, 4 * IMG);
+	for (int i = threadIdx.x; i < a.Sq * a.dh; i += 256) dq_s[i] = 0.f;
+	const float c = a.scale * LOG2E;
+	for (int k0 = 0; k0 < a.Skv; k0 += 64) {
+		__syncthreads();  // the previous key block's readers are done with every image (and the fills above are complete)
+		if (k0 > 0) zero_lds(Vs, IMG);  // (it held dS values in columns past the head size)
+		__syncthreads();
+		stage_rows(Ks, kb, a.ldk, k0, a.Skv, dh4);
+		stage_rows(Vs, vb, a.ldv, k0, a.Skv, dh4);
+		__syncthreads();
+		bf16x8 kf[KS], vf[KS];
+#pragma unroll
+		for (int s = 0; s < KS; ++s) {
+			kf[s] = row_frag(Ks, 16 * wave, s, lane);
+			vf[s] = row_frag(Vs, 16 * wave, s, lane);
+		}
+		const int key = k0 + 16 * wave + (lane & 15);
+		const bool key_ok = key < a.Skv;
+		f32x4 dk[NDT], dv[NDT];
+#pragma unroll
+		for (int dt = 0; dt < NDT; ++dt) dk[dt] = dv[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+		uint2 qr[NDT], gr[NDT];
+		float stat = 0.f;  // threads 0..63: lse of query q0 + t; 64..127: delta of query q0 + t - 64
+		auto fetch_stat = [&](int q0) {
+			if (threadIdx.x < 128) {
+				const int q = q0 + (threadIdx.x & 63);
+				const bool is_lse = threadIdx.x < 64;
+				stat = q < a.Sq ? a.bwd_scratch[((int64_t)(is_lse ? 0 : n_bh) + bh) * a.Sq + q] : (is_lse ? INFINITY : 0.f);  // padded queries: probability 0
+			}
+		};
+		fetch_rows(qr, qb, a.ldq, 0, a.Sq, dh4);
+		fetch_rows(gr, gb, a.ldo, 0, a.Sq, dh4);
+		fetch_stat(0);
+		for (int q0 = 0; q0 < a.Sq; q0 += 64) {
+			__syncthreads();  // every wave has its V fragments / is done with the previous query block's Q, dO and dS images
+			commit_rows(Qs, qr, dh4);
+			commit_rows(Gs, gr, dh4);
+			if (threadIdx.x < 128) lse_s[threadIdx.x] = stat;  // delta_s follows lse_s
+			if constexpr (DROP) {
+				if (threadIdx.x >= 192) rk_s[threadIdx.x - 192] = attn_row_key(attn_head_key(a, bh), q0 + (int)threadIdx.x - 192);
+			}
+			__syncthreads();
+			if (q0 + 64 < a.Sq) {
+				fetch_rows(qr, qb, a.ldq, q0 + 64, a.Sq, dh4);
+				fetch_rows(gr, gb, a.ldo, q0 + 64, a.Sq, dh4);
+				fetch_stat(q0 + 64);
+			}
+#pragma unroll
+			for (int u = 0; u < 2; ++u) {
+				f32x4 pr[2], ds[2];
+#pragma unroll
+				for (int hf = 0; hf < 2; ++hf) {
+					const int t = 2 * u + hf;
+					f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+					for (int ks = 0; ks < KS; ++ks) {
+						s = mfma16(row_frag(Qs, 16 * t, ks, lane), kf[ks], s);
+						dp = mfma16(row_frag(Gs, 16 * t, ks, lane), vf[ks], dp);
+					}
+					const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_s + 16 * t + 4 * g);
+					const f32x4 d4 = *reinterpret_cast<const f32x4*>(delta_s + 16 * t + 4 * g);
+					float keep[4] = {1.f, 1.f, 1.f, 1.f};
+					if constexpr (DROP) {
+						const uint4 rk4 = *reinterpret_cast<const uint4*>(rk_s + 16 * t + 4 * g);
+						keep[0] = attn_keep(attn_pair_bits(rk4.x, key >> 1), key, a.drop_thr16, a.drop_scale);
+						keep[1] = attn_keep(attn_pair_bits(rk4.y, key >> 1), key, a.drop_thr16, a.drop_scale);
+						keep[2] = attn_keep(attn_pair_bits(rk4.z, key >> 1), key, a.drop_thr16, a.drop_scale);
+						keep[3] = attn_keep(attn_pair_bits(rk4.w, key >> 1), key, a.drop_thr16, a.drop_scale);
+					}
+#pragma unroll
+					for (int r = 0; r < 4; ++r) {
+						const float p = key_ok ? __builtin_amdgcn_exp2f(s[r] * c - l4[r]) : 0.f;  // (a key past the last must not reach dQ)
+						pr[hf][r] = DROP ? p * keep[r] : p;
+						ds[hf][r] = p * ((DROP ? dp[r] * keep[r] : dp[r]) - d4[r]) * a.scale;
+					}
+					// dS of this lane's key, queries 16 t + 4 g .. + 3, into the [key][query] image
+					bf16x4 d16;
+#pragma unroll
+					for (int r = 0; r < 4; ++r) d16[r] = (bf16_t)ds[hf][r];
+					const int qc = 16 * t + 4 * g;
+					*reinterpret_cast<bf16x4*>(DSs + img_off(16 * wave + (lane & 15), qc >> 3) + (((qc >> 2) & 1) << 3)) = d16;
+				}
+				const bf16x8 pf = pack8(pr[0], pr[1]), dsf = pack8(ds[0], ds[1]);
+#pragma unroll
+				for (int dt = 0; dt < NDT; ++dt) {
+					dv[dt] = mfma16(tr_frag(Gs, 32 * u, 32 * u + 16, 16 * dt, lane), pf, dv[dt]);
+					dk[dt] = mfma16(tr_frag(Qs, 32 * u, 32 * u + 16, 16 * dt, lane), dsf, dk[dt]);
+				}
+			}
+			__syncthreads();  // the dS image is complete
+			// dQ^T (this key block's part) of the wave's 16 queries: rows d, query on the lane
+			const int q = q0 + 16 * wave + (lane & 15);
+#pragma unroll
+			for (int dt = 0; dt < NDT; ++dt) {
+				f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+				for (int u = 0; u < 2; ++u) acc = mfma16(tr_frag(Ks, 32 * u, 32 * u + 16, 16 * dt, lane), tr_frag(DSs, 32 * u, 32 * u + 16, 16 * wave, lane), acc);
+				const int d0 = 16 * dt + 4 * g;
+				if (q < a.Sq && d0 < a.dh) {
+					f32x4* dst = reinterpret_cast<f32x4*>(dq_s + q * a.dh + d0);
+					*dst = *dst + acc;
+				}
+			}
+		}
+		if (key_ok) {
+			bf16_t* dkp = reinterpret_cast<bf16_t*>(a.dk) + ((int64_t)b * a.Skv + key) * a.lddk + h * a.dh;
+			bf16_t* dvp = reinterpret_cast<bf16_t*>(a.dv) + ((int64_t)b * a.Skv + key) * a.lddv + h * a.dh;
+#pragma unroll
+			for (int dt = 0; dt < NDT; ++dt) {
+				store4(dkp, 16 * dt + 4 * g, a.dh, dk[dt], 1.f);
+				store4(dvp, 16 * dt + 4 * g, a.dh, dv[dt], 1.f);
+			}
+		}
+	}
+	__syncthreads();
+	bf16_t* dqb = reinterpret_cast<bf16_t*>(a.dq) + (int64_t)b * a.Sq * a.lddq + h * a.dh;
+	for (int idx = threadIdx.x; idx < a.Sq * dh4; idx += 256) {
+		const int q = idx / dh4, c4 = idx - q * dh4;
+		const f32x4 v = *reinterpret_cast<const f32x4*>(dq_s + q * a.dh + 4 * c4);
+		bf16x4 o;
+#pragma unroll
+		for (int r = 0; r < 4; ++r) o[r] = (bf16_t)v[r];
+		*reinterpret_cast<bf16x4*>(dqb + (int64_t)q * a.lddq + 4 * c4) = o;
+	}
+}
+
+// LDS of the one-pass backward: four images, the per-block statistics, dQ of the whole head in float32
+inline size_t bwd1_lds(const AttnArgs& a) { return (size_t)4 * IMG + 3 * 64 * 4 + (size_t)a.Sq * a.dh * 4; }
+
 template <int KS, int NDT, bool DROP>
 int run_d(const AttnArgs& a, bool bwd, hipStream_t st) {
 	const unsigned n_bh = (unsigned)(a.B * a.n_head);
 	if (!bwd) {
 		hipLaunchKernelGGL((attn_flash_fwd_kernel<KS, NDT, DROP>), dim3((unsigned)vitk_cdiv(a.Sq, 64), n_bh), dim3(256), 0, st, a);
+		VITK_CHECK_LAUNCH();
+		return VITK_OK;
+	}
+	// small heads over a sequence whose dQ fits LDS beside the images with two workgroups per CU: the one-pass form
+	static const bool one_pass = getenv("VITK_ATTN_FLASH_ONE_PASS") == nullptr || getenv("VITK_ATTN_FLASH_ONE_PASS")[0] != '0';  // A-B switch
+	// (measured per layer of the conv + attention hybrid at batch 128: 196 tokens x 16 heads of 24: 558 -> 418 us; 784 tokens x 32
+	// heads of 12: 2568 -> 2614 us -- with 13 key blocks the three barriers per (key block, query block) pair at two workgroups
+	// per CU cost what the second softmax saved, so long sequences keep the two-kernel form)
+	if (one_pass && NDT <= 2 && a.Skv <= 256 && bwd1_lds(a) <= 80 * 1024) {
+		const size_t lds = bwd1_lds(a);
+		static bool attr_set = false;
+		if (!attr_set) {
+			hipError_t e = hipFuncSetAttribute((const void*)attn_flash_bwd1_kernel<KS, NDT, DROP>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+			if (e != hipSuccess) return VITK_ERR_HIP - (int)e;
+			attr_set = true;
+		}
+		hipLaunchKernelGGL(attn_flash_delta_kernel, dim3((unsigned)vitk_cdiv((int64_t)n_bh * a.Sq, 256)), dim3(256), 0, st, a);
+		VITK_CHECK_LAUNCH();
+		hipLaunchKernelGGL((attn_flash_bwd1_kernel<KS, NDT, DROP>), dim3(n_bh), dim3(256), lds, st, a);
 		VITK_CHECK_LAUNCH();
 		return VITK_OK;
 	}
