@@ -762,6 +762,8 @@ int vitk_gemm_bf16(const vitk_gemm_desc& d, hipStream_t st, bool* colsum_done) {
 	const int64_t t256n = vitk_cdiv(d.M, 256) * vitk_cdiv(d.N, 256);
 	const bool starved = small_rule && d.out_dtype == VITK_BF16 && t256n < 128;  // (thresholds 64 ... 256 measured the same on the CvT step: 7.9 -> 6.6 ms)
 	static const bool p8 = getenv("VITK_NO_P8") == nullptr;  // A-B switch
+	static const bool force_t128 = getenv("VITK_FORCE_T128") != nullptr;  // diagnosis: every problem the 128x256-tile kernel takes runs on it
+	if (force_t128 && vitk_gemm_bf16_t128_ok(d) && d.a_colsum == nullptr) return vitk_gemm_bf16_t128(d, st);
 	// (at least 64 tiles' worth of output: measured on the 32 x 32 models, 32 / 64 / 100 tiles as the bound: CvT 4.09 / 4.04 / 4.04 ms,
 	// ViT-Tiny 4.91 / 4.91 / 5.64 ms per step)
 	if (p8 && big_tiles && d.a_colsum == nullptr && vitk_gemm_bf16_p8_ok(d) && d.M * d.N >= 64ll * 256 * 256) {
