@@ -58,6 +58,20 @@ int main() {
 	d.drop_p[0] = 0.5f;
 	EXPECT_NEG(vitk_gemm(&d, nullptr));  // dropout without an activation / residual epilogue
 	d.drop_p[0] = 0.f;
+	{  // several products in one call: every descriptor is checked before anything is launched
+		vitk_gemm_desc two[2];
+		two[0] = d;
+		two[1] = d;
+		two[0].in_dtype = two[0].out_dtype = two[1].in_dtype = two[1].out_dtype = VITK_F32;
+		two[1].ldc = 1;  // the SECOND one is malformed
+		EXPECT_NEG(vitk_gemm_group(two, 2, nullptr));
+		EXPECT_NEG(vitk_gemm_group(nullptr, 2, nullptr));
+		EXPECT_NEG(vitk_gemm_group(two, -1, nullptr));
+		if (vitk_gemm_group(nullptr, 0, nullptr) != 0) {
+			std::printf("FAIL vitk_gemm_group of nothing\n");
+			++failures;
+		}
+	}
 	d.epilogue = VITK_EPI_RESIDUAL;
 	EXPECT_NEG(vitk_gemm(&d, nullptr));  // residual epilogue without aux
 	d.epilogue = VITK_EPI_NONE;
@@ -87,6 +101,12 @@ int main() {
 	EXPECT_NEG(vitk_dual_head_fwd(p, p, f, p, f, p, p, 4, 1, 64, 10, VITK_BF16, nullptr));  // fewer than two token rows
 	EXPECT_NEG(vitk_ce_kd_loss(p, nullptr, nullptr, f, p, 4, 10, 0.f, 0.f, 1.f, VITK_F32, nullptr));
 	EXPECT_NEG(vitk_ce_kd_loss(p, reinterpret_cast<const int64_t*>(buf), nullptr, f, p, 4, 10, 0.f, 0.f, 0.f, VITK_F32, nullptr));  // tau = 0
+	EXPECT_NEG(vitk_batchnorm_act_fwd(nullptr, f, f, f, f, p, f, f, 64, 8, 1e-5f, 0.1f, 1, VITK_ACT_GELU, VITK_BF16, nullptr, 0, nullptr));
+	EXPECT_NEG(vitk_batchnorm_act_fwd(p, f, f, f, f, p, f, f, 64, 8, 1e-5f, 0.1f, 1, 9, VITK_BF16, nullptr, 0, nullptr));               // unknown activation
+	EXPECT_NEG(vitk_batchnorm_act_fwd(p, f, f, f, f, p, f, f, 64, 12, 1e-5f, 0.1f, 1, VITK_ACT_GELU, VITK_BF16, nullptr, 0, nullptr));  // channels not in 16-byte groups
+	EXPECT_NEG(vitk_batchnorm_act_bwd(p, p, f, nullptr, f, f, p, f, f, 64, 8, 1, VITK_ACT_SILU, VITK_BF16, nullptr, 0, nullptr));       // the activation needs beta
+	EXPECT_NEG(vitk_dwconv_bwd_acc(p, p, 8, p, p, 8, nullptr, 1, 1, 4, 4, 8, 3, 1, 1, VITK_BF16, nullptr));
+	EXPECT_NEG(vitk_dwconv_bwd_acc(p, p, 4, p, p, 8, f, 1, 1, 4, 4, 8, 3, 1, 1, VITK_BF16, nullptr));  // row stride below the channel count
 	std::printf(failures == 0 ? "abi validation: all calls rejected as expected\n" : "abi validation: %d failures\n", failures);
 	return failures == 0 ? 0 : 1;
 }
